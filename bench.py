@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ESRGAN RRDBNet x4 bf16 inference throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step is one GeneratorRRDB forward over one batch of synthetic LR patches already resident in
+HBM (BASELINE.json configs[1]: 16 x 3x128x128 -> 16 x 3x512x512, 23 RRDB, bf16 kernels).  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own batch — the
+path shards by independent patches with no data-path collective — and the value is the job
+aggregate over max-over-ranks time ("weak" scaling).  Rank 0 prints ONE JSON line.
+
+Besides the throughput the line carries
+* ``roofline``: for the conv3x3 MFMA kernel instantiation with the largest time share, the
+  algorithmic FLOPs of its launches in one forward divided by their measured durations
+  (HIP events on the launch stream), against the 2.5 PFLOP/s dense bf16 peak;
+* ``cpu_baseline``: the CPU oracle (a port of the reference PyTorch forward) timed on this
+  box's host cores on one patch of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (no sparsity)
+FLOP_PER_LR_PIXEL = 35_853_696  # 2 * 17,926,848 MAC for the default generator
+
+
+def conv_flops(cin, cout, pixels):
+    return 2.0 * 9 * cin * cout * pixels
+
+
+def measure_kernels(net, N, H, W, reps=10):
+    """Time every distinct conv launch configuration of one forward on cfg-sized buffers and
+    aggregate per kernel instantiation (Cout<=32 -> MB=1 symbol, Cout 64 -> MB=2 symbol)."""
+    import super_resolution_amd as S
+    from super_resolution_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dt = S.DTYPE_BF16
+    nf, gc, nb = net.num_features, net.growth_channels, net.num_blocks
+    rdb = net.body[0].rdb1
+    packed = [ops.pack_weight(c.weight.detach(), c.bias.detach(), dt) for c in rdb._convs()]
+    buf = torch.zeros((N, H, (nf + 4 * gc) // 8, W, 8), dtype=torch.bfloat16, device=dev).normal_()
+    nxt = torch.empty_like(buf)
+    trunk = torch.zeros((N, H, nf // 4, W, 4), dtype=torch.float32, device=dev).normal_()
+    outer = trunk.clone()
+    P = N * H * W
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    rows = []   # (symbol, name, launches per forward, flops per launch, seconds per launch)
+    for k in range(4):
+        wp, bp = packed[k]
+        cu = (nf + k * gc) // 8
+        tk = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, gc, 0.2, 0, None, 0.0, None, 0.0, buf, cu, None, None))
+        rows.append(("MB1", f"conv{k + 1} {nf + k * gc}->{gc}", 3 * nb, conv_flops(nf + k * gc, gc, P), tk))
+    wp, bp = packed[4]
+    cu = (nf + 4 * gc) // 8
+    t5 = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None))
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5))
+    t5b = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None))
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b))
+    # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
+    w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt)
+    wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt)
+    lr = torch.zeros((N, H, nf // 8, W, 8), dtype=torch.bfloat16, device=dev).normal_()
+    h1 = torch.empty((N, 2 * H, nf // 8, 2 * W, 8), dtype=torch.bfloat16, device=dev)
+    h2 = torch.empty((N, 4 * H, nf // 8, 4 * W, 8), dtype=torch.bfloat16, device=dev)
+    h3 = torch.empty_like(h2)
+    out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
+    nu = nf // 8
+    ta = timed(lambda: ops.conv3x3_fwd(lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None))
+    rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta))
+    tb = timed(lambda: ops.conv3x3_fwd(h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None))
+    rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb))
+    tc = timed(lambda: ops.conv3x3_fwd(h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None))
+    rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc))
+    td = timed(lambda: ops.conv3x3_fwd(h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out))
+    rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td))
+    tt = timed(lambda: ops.conv3x3_fwd(buf, nu, w64, b64, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None))
+    rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt))
+    return rows
+
+
+def roofline_from(rows):
+    agg = {}
+    for sym, _name, cnt, fl, sec in rows:
+        a = agg.setdefault(sym, [0, 0.0, 0.0])
+        a[0] += cnt
+        a[1] += cnt * fl
+        a[2] += cnt * sec
+    out = {}
+    for sym, (cnt, fl, sec) in agg.items():
+        out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6,
+                    "flop_per_launch": fl / cnt, "achieved": fl / sec / 1e12, "time_s": sec}
+    dom = max(out, key=lambda s: out[s]["time_s"])
+    names = {"MB1": "conv3x3_mfma<bf16,MB=1,NB=4,SU=2> (Cout<=32)", "MB2": "conv3x3_mfma<bf16,MB=2,NB=4,SU=2> (Cout=64)"}
+    d = out[dom]
+    roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
+            "flop_per_launch": d["flop_per_launch"]}
+    other = {names[s]: {"achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / PEAK_BF16_TFLOPS, 4),
+                        "avg_launch_us": round(v["avg_launch_us"], 2)} for s, v in out.items() if s != dom}
+    per_shape = [{"kernel": sym, "shape": name, "us": round(sec * 1e6, 2), "tflops": round(fl / sec / 1e12, 1)}
+                 for sym, name, _c, fl, sec in rows]
+    return roof, other, per_shape
+
+
+def cpu_baseline(H, W):
+    """The oracle on the host cores, one patch of the benchmark workload (same generator, fp32)."""
+    from oracle import esrgan_oracle as O
+    sd = O.make_generator_state(0)
+    x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        O.generator_forward(sd, x)           # warm-up
+        times = []
+        t_end = time.time() + 20.0
+        while len(times) < 5 and (time.time() < t_end or len(times) < 2):
+            t0 = time.perf_counter()
+            O.generator_forward(sd, x)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(16 * H * W / med / 1e6, 4), "unit": "HR Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"1 of the 16 patches (1x3x{H}x{W} fp32), median of {len(times)} forwards after 1 warm-up, "
+                      f"{med:.3f} s each, torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=128, help="LR patch height = width")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import super_resolution_amd as S
+    torch.manual_seed(0)
+    net = S.GeneratorRRDB(precision="bf16").to(dev).eval()
+    B, H, W = args.batch, args.size, args.size
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(x)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(x)
+        sync()
+        elapsed = time.perf_counter() - t0
+    assert out.shape == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(out).all())
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms = elapsed / args.steps * 1e3
+    hr_mpix = world * B * 16 * H * W * args.steps / elapsed / 1e6
+    line = {
+        "metric": "RRDBNet x4 HR Mpix/s (infer)", "value": round(hr_mpix, 2), "unit": "HR Mpix/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"configs[1]: RRDBNet x4 (nf=64, 23 RRDB) bf16 inference, batch {B} of 3x{H}x{W} "
+                               f"LR patches per GPU -> 3x{4 * H}x{4 * W}, inputs resident in HBM",
+                   "batch_per_gpu": B, "lr_size": [H, W], "parallelism": f"patch-sharded x{world}, no collective"},
+        "generator_tflops": round(world * B * H * W * FLOP_PER_LR_PIXEL * args.steps / elapsed / 1e12, 1),
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            with torch.no_grad():
+                roof, other, per_shape = roofline_from(measure_kernels(net, B, H, W))
+            line["roofline"] = roof
+            line["roofline_other_kernels"] = other
+            line["kernel_shapes"] = per_shape
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(H, W)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+/*
+ * sr355 — MI355X (gfx950) native kernels for the ESRGAN x4 generator hot path.
+ *
+ * C ABI of libsr355.so.  Plain pointers and sizes only; every pointer named *_dev is a
+ * device pointer owned by the caller (PyTorch's allocator in the Python host); the library
+ * never allocates, frees or retains device memory.  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  Every function returns SR355_OK or a negative error
+ * code; sr355_last_error() returns the message of the calling thread's last failure.
+ *
+ * Reference interfaces replaced (all in /root/reference/esrgan/models/esrgan_model.py):
+ *   nn.Conv2d(cin,cout,3,1,1) + torch.cat + LeakyReLU + scaled skip   :10-24
+ *   RRDB skip                                                          :35-39
+ *   GeneratorRRDB.forward                                              :55-62
+ *   F.interpolate(nearest, x2) feeding a conv                          :59-60
+ *
+ * Activation layout ("blocked"): [N][H][U][W][16 bytes] where one 16-byte unit holds
+ * 8 consecutive channels in bf16 mode or 4 in fp32 mode and U = channels / (8|4).
+ * A dense block keeps x and its four growth outputs in ONE such buffer (U = 24 in bf16,
+ * channels 0..191); each conv reads units [0, cin_units) and writes its result at a unit
+ * offset, so no concatenation is ever materialised.
+ * fp32 "trunk" tensors (residual carriers) use the same layout with 4-channel units.
+ */
+#ifndef SR355_H
+#define SR355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR355_OK 0
+#define SR355_ERR_INVALID (-1)   /* bad argument / shape / alignment / size   */
+#define SR355_ERR_HIP (-2)       /* HIP runtime or launch failure             */
+#define SR355_ERR_UNSUPPORTED (-3)
+
+#define SR355_DTYPE_BF16 0       /* bf16 storage, fp32 accumulate (32x32x16 MFMA) */
+#define SR355_DTYPE_F32 1        /* fp32 storage, exact fp32 MFMA (32x32x2)        */
+
+#define SR355_ABI_VERSION 1
+
+int sr355_abi_version(void);
+const char *sr355_last_error(void);
+
+/* Channels per 16-byte unit for a dtype (8 or 4); <0 on bad dtype. */
+int sr355_unit_channels(int dtype);
+
+/* ---- layout conversion (module boundary: NCHW fp32 tensors, esrgan_model.py:55,:62) ---- */
+
+/* src [N][C][H][W] fp32 -> dst blocked [N][H][dst_units][W][unit]; channels >= C are zero. */
+int sr355_nchw_to_blocked(const float *src_dev, int N, int C, int H, int W, int dtype,
+                          void *dst_dev, int dst_units, size_t dst_bytes, void *stream);
+/* blocked units [unit_off, unit_off + ceil(C/unit)) -> dst [N][C][H][W] fp32. */
+int sr355_blocked_to_nchw(const void *src_dev, int src_units, int unit_off, int dtype,
+                          int N, int C, int H, int W, float *dst_dev, size_t dst_bytes,
+                          void *stream);
+
+/* ---- weights: OIHW fp32 (the state_dict layout, kept as the parameter) -> packed ---- */
+
+/* Packed layout [cin_units][9][cout_pad][unit]; cout_pad = round_up(cout, 32),
+ * cin_units = round_up(ceil(cin/unit), 2).  Returns bytes (0 on bad args). */
+size_t sr355_packed_weight_bytes(int cout, int cin, int dtype);
+/* bias_packed_dev receives cout_pad floats (zero padded).  */
+int sr355_pack_weight(const float *w_oihw_dev, const float *bias_dev, int cout, int cin,
+                      int dtype, void *w_packed_dev, size_t w_packed_bytes,
+                      float *bias_packed_dev, void *stream);
+
+/* ---- the convolution op (replaces nn.Conv2d 3x3/s1/p1 + its fused neighbours) ---- */
+typedef struct sr355_conv_args {
+    int dtype;                 /* SR355_DTYPE_*                                            */
+    int N, H, W;               /* OUTPUT batch / height / width                            */
+    int upsample;              /* 1: input is [N][H/2][..][W/2], nearest x2 fused on load   */
+    const void *in_dev;        /* blocked activations                                      */
+    size_t in_bytes;
+    int in_units;              /* units per pixel of the input buffer                      */
+    int cin_units;             /* units consumed: channels [0, cin_units*unit); even       */
+    const void *w_packed_dev;  /* sr355_pack_weight output                                 */
+    size_t w_packed_bytes;
+    const float *bias_packed_dev;
+    int cout;                  /* real output channels                                     */
+    float lrelu_slope;         /* 1.0f = no activation                                     */
+    /* v = conv + bias; v = lrelu(v); if res1: v = res1 + res1_scale*v;
+     * if res2: v = res2 + res2_scale*v   (res*: fp32 trunk tensors, cout channels)       */
+    const float *res1_dev; float res1_scale;
+    const float *res2_dev; float res2_scale;
+    size_t res_bytes;          /* size of each residual / out_f32 tensor                   */
+    /* outputs (any subset, at least one) */
+    void *out_act_dev;         /* blocked, dtype storage, written at out_unit_off          */
+    size_t out_act_bytes;
+    int out_units, out_unit_off;
+    float *out_f32_dev;        /* fp32 trunk [N][H][cout/4][W][4]                           */
+    float *out_nchw_dev;       /* [N][cout][H][W] fp32                                     */
+    size_t out_nchw_bytes;
+} sr355_conv_args;
+
+int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
+
+/* ---- whole generator (GeneratorRRDB.forward, esrgan_model.py:55-62) ---- */
+typedef struct sr355_generator_cfg {
+    int in_channels, out_channels, num_features, num_blocks, growth_channels; /* :42 */
+    int dtype;
+    int trunk_fp32;            /* 1: residual trunk carried in fp32 beside the bf16 copy  */
+} sr355_generator_cfg;
+
+/* Number of 3x3 convs (351 for the default config). */
+int sr355_generator_num_convs(const sr355_generator_cfg *cfg);
+/* Bytes of the packed parameter blob (all packed weights + padded biases). */
+size_t sr355_generator_packed_bytes(const sr355_generator_cfg *cfg);
+/* w_ptrs/b_ptrs: device pointers to the OIHW fp32 weights / biases in state_dict order. */
+int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_ptrs,
+                         const float *const *b_ptrs, int n_convs, void *packed_dev,
+                         size_t packed_bytes, void *stream);
+size_t sr355_generator_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W);
+/* in [N][in_channels][H][W] fp32 -> out [N][out_channels][4H][4W] fp32 (unclamped). */
+int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed_dev,
+                            size_t packed_bytes, const float *in_nchw_dev, float *out_nchw_dev,
+                            int N, int H, int W, void *workspace_dev, size_t workspace_bytes,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR355_H */

@@ -1,0 +1,7 @@
+"""MI355X-native ESRGAN x4 generator hot path (HIP kernels behind the reference's module API)."""
+from ._lib import DTYPE_BF16, DTYPE_F32, LIB_PATH, Sr355Error, build  # noqa: F401
+from . import ops  # noqa: F401  (registers the sr355:: torch.library ops)
+from .esrgan_model import GeneratorRRDB, RRDB, RRDBNet, ResidualDenseBlock  # noqa: F401
+
+__all__ = ["GeneratorRRDB", "RRDBNet", "RRDB", "ResidualDenseBlock", "ops", "build",
+           "DTYPE_BF16", "DTYPE_F32", "LIB_PATH", "Sr355Error"]

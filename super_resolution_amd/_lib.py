@@ -1,0 +1,112 @@
+"""ctypes binding of libsr355.so (C ABI declared in include/sr355.h).
+
+The library is built in-tree by ``super_resolution_amd/csrc/Makefile``.  There is no
+fallback: if the shared object is missing, loading raises and every op fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr355.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+DTYPE_BF16 = 0
+DTYPE_F32 = 1
+ABI_VERSION = 1
+
+# every symbol include/sr355.h declares
+EXPORTS = (
+    "sr355_abi_version", "sr355_last_error", "sr355_unit_channels",
+    "sr355_nchw_to_blocked", "sr355_blocked_to_nchw",
+    "sr355_packed_weight_bytes", "sr355_pack_weight",
+    "sr355_conv3x3_fwd",
+    "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
+    "sr355_generator_workspace_bytes", "sr355_generator_forward",
+)
+
+
+class ConvArgs(C.Structure):
+    """Mirror of ``sr355_conv_args``."""
+    _fields_ = [
+        ("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("upsample", C.c_int),
+        ("in_dev", C.c_void_p), ("in_bytes", C.c_size_t),
+        ("in_units", C.c_int), ("cin_units", C.c_int),
+        ("w_packed_dev", C.c_void_p), ("w_packed_bytes", C.c_size_t),
+        ("bias_packed_dev", C.c_void_p),
+        ("cout", C.c_int), ("lrelu_slope", C.c_float),
+        ("res1_dev", C.c_void_p), ("res1_scale", C.c_float),
+        ("res2_dev", C.c_void_p), ("res2_scale", C.c_float),
+        ("res_bytes", C.c_size_t),
+        ("out_act_dev", C.c_void_p), ("out_act_bytes", C.c_size_t),
+        ("out_units", C.c_int), ("out_unit_off", C.c_int),
+        ("out_f32_dev", C.c_void_p),
+        ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
+    ]
+
+
+class GeneratorCfg(C.Structure):
+    """Mirror of ``sr355_generator_cfg``."""
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("num_features", C.c_int),
+        ("num_blocks", C.c_int), ("growth_channels", C.c_int), ("dtype", C.c_int),
+        ("trunk_fp32", C.c_int),
+    ]
+
+
+class Sr355Error(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libsr355.so for gfx950 with hipcc (works without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode:
+        print(res.stdout)
+    if res.returncode:
+        raise Sr355Error(f"building libsr355.so failed (exit {res.returncode})")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Sr355Error(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    L.sr355_abi_version.restype = i
+    L.sr355_last_error.restype = C.c_char_p
+    L.sr355_unit_channels.argtypes = [i]
+    L.sr355_nchw_to_blocked.argtypes = [vp, i, i, i, i, i, vp, i, sz, vp]
+    L.sr355_blocked_to_nchw.argtypes = [vp, i, i, i, i, i, i, i, vp, sz, vp]
+    L.sr355_packed_weight_bytes.argtypes = [i, i, i]
+    L.sr355_packed_weight_bytes.restype = sz
+    L.sr355_pack_weight.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
+    L.sr355_conv3x3_fwd.argtypes = [C.POINTER(ConvArgs), vp]
+    L.sr355_generator_num_convs.argtypes = [C.POINTER(GeneratorCfg)]
+    L.sr355_generator_packed_bytes.argtypes = [C.POINTER(GeneratorCfg)]
+    L.sr355_generator_packed_bytes.restype = sz
+    L.sr355_generator_pack.argtypes = [C.POINTER(GeneratorCfg), C.POINTER(vp), C.POINTER(vp), i, vp, sz, vp]
+    L.sr355_generator_workspace_bytes.argtypes = [C.POINTER(GeneratorCfg), i, i, i]
+    L.sr355_generator_workspace_bytes.restype = sz
+    L.sr355_generator_forward.argtypes = [C.POINTER(GeneratorCfg), vp, sz, vp, vp, i, i, i, vp, sz, vp]
+    if L.sr355_abi_version() != ABI_VERSION:
+        raise Sr355Error(f"libsr355.so ABI {L.sr355_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().sr355_last_error().decode("utf-8", "replace")
+        raise Sr355Error(f"{what} failed ({rc}): {msg}")

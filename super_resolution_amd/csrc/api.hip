@@ -1,0 +1,422 @@
+// C ABI of libsr355.so (declared in include/sr355.h) and the generator schedule.
+//
+// The schedule in sr355_generator_forward follows GeneratorRRDB.forward
+// (/root/reference/esrgan/models/esrgan_model.py:55-62): conv_first, num_blocks x RRDB
+// (3 dense blocks of 5 convs, :18-24, :35-39), trunk_conv + global skip, two
+// nearest-x2 + conv + LeakyReLU stages, HR_conv + LeakyReLU, conv_last.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sr355_internal.h"
+
+namespace sr355 {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return SR355_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SR355_ERR_HIP;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- generator geometry -------------------------------------------------------------------
+struct ConvSpec {
+    int cin, cout;
+    size_t w_off, b_off;  // offsets into the packed blob
+};
+
+static bool cfg_ok(const sr355_generator_cfg *c) {
+    if (!c) {
+        set_error("generator cfg is null");
+        return false;
+    }
+    if (unit_channels(c->dtype) < 0) {
+        set_error("generator cfg: unknown dtype %d", c->dtype);
+        return false;
+    }
+    if (c->in_channels < 1 || c->out_channels < 1 || c->num_blocks < 0 || c->num_features < 16 ||
+        c->growth_channels < 16 || (c->num_features % 16) || (c->growth_channels % 16)) {
+        set_error("generator cfg: need in/out channels >= 1, num_blocks >= 0 and num_features / "
+                  "growth_channels positive multiples of 16 (got in=%d out=%d nf=%d nb=%d gc=%d)",
+                  c->in_channels, c->out_channels, c->num_features, c->num_blocks, c->growth_channels);
+        return false;
+    }
+    return true;
+}
+
+// Convs in state_dict order (constructor order of esrgan_model.py:42-53).
+static std::vector<ConvSpec> conv_specs(const sr355_generator_cfg &c, size_t *total_bytes) {
+    std::vector<ConvSpec> v;
+    const int nf = c.num_features, gc = c.growth_channels;
+    v.push_back({c.in_channels, nf, 0, 0});
+    for (int b = 0; b < c.num_blocks; ++b)
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 5; ++k) v.push_back({nf + gc * k, k < 4 ? gc : nf, 0, 0});
+    for (int i = 0; i < 4; ++i) v.push_back({nf, nf, 0, 0});
+    v.push_back({nf, c.out_channels, 0, 0});
+    size_t off = 0;
+    for (auto &s : v) {
+        s.w_off = off;
+        off += align256(sr355_packed_weight_bytes(s.cout, s.cin, c.dtype));
+        s.b_off = off;
+        off += align256((size_t)cout_pad_for(s.cout) * sizeof(float));
+    }
+    if (total_bytes) *total_bytes = off;
+    return v;
+}
+
+struct Workspace {
+    size_t x0, bufA, bufB, T, R, F, L1, H1, H2, H3, total;
+    int in_units, nf_units, blk_units, f32_units;
+};
+
+static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
+    Workspace w;
+    const int cpu = unit_channels(c.dtype);
+    const size_t P = (size_t)N * H * W;
+    w.in_units = cin_units_for(c.in_channels, c.dtype);
+    w.nf_units = c.num_features / cpu;
+    w.blk_units = (c.num_features + 4 * c.growth_channels) / cpu;
+    w.f32_units = c.num_features / 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    w.x0 = take(P * w.in_units * 16);
+    w.bufA = take(P * w.blk_units * 16);
+    w.bufB = take(P * w.blk_units * 16);
+    w.T = take(P * c.num_features * 4);
+    w.R = take(P * c.num_features * 4);
+    w.F = take(P * c.num_features * 4);
+    w.L1 = take(P * w.nf_units * 16);
+    w.H1 = take(4 * P * w.nf_units * 16);
+    w.H2 = take(16 * P * w.nf_units * 16);
+    w.H3 = take(16 * P * w.nf_units * 16);
+    w.total = off;
+    return w;
+}
+
+}  // namespace sr355
+
+using namespace sr355;
+
+extern "C" {
+
+int sr355_abi_version(void) { return SR355_ABI_VERSION; }
+const char *sr355_last_error(void) { return g_err; }
+int sr355_unit_channels(int dtype) { return unit_channels(dtype); }
+
+int sr355_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst, int dst_units,
+                          size_t dst_bytes, void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (cpu < 0 || !src || !dst || N < 1 || C < 1 || H < 1 || W < 1 || dst_units * cpu < C) {
+        set_error("nchw_to_blocked: bad arguments (dtype=%d N=%d C=%d H=%d W=%d units=%d)", dtype, N, C, H, W,
+                  dst_units);
+        return SR355_ERR_INVALID;
+    }
+    if (!aligned16(dst) || dst_bytes < (size_t)N * H * dst_units * W * 16) {
+        set_error("nchw_to_blocked: destination too small or not 16-byte aligned");
+        return SR355_ERR_INVALID;
+    }
+    return launch_nchw_to_blocked(src, N, C, H, W, dtype, dst, dst_units, (hipStream_t)stream);
+}
+
+int sr355_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C, int H, int W,
+                          float *dst, size_t dst_bytes, void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (cpu < 0 || !src || !dst || N < 1 || C < 1 || H < 1 || W < 1 || unit_off < 0 ||
+        (unit_off + (C + cpu - 1) / cpu) > src_units) {
+        set_error("blocked_to_nchw: bad arguments (dtype=%d N=%d C=%d H=%d W=%d units=%d off=%d)", dtype, N, C,
+                  H, W, src_units, unit_off);
+        return SR355_ERR_INVALID;
+    }
+    if (dst_bytes < (size_t)N * C * H * W * sizeof(float)) {
+        set_error("blocked_to_nchw: destination too small");
+        return SR355_ERR_INVALID;
+    }
+    return launch_blocked_to_nchw(src, src_units, unit_off, dtype, N, C, H, W, dst, (hipStream_t)stream);
+}
+
+size_t sr355_packed_weight_bytes(int cout, int cin, int dtype) {
+    if (unit_channels(dtype) < 0 || cout < 1 || cin < 1) return 0;
+    return (size_t)cin_units_for(cin, dtype) * 9 * cout_pad_for(cout) * 16;
+}
+
+int sr355_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp, size_t wp_bytes,
+                      float *bp, void *stream) {
+    const size_t need = sr355_packed_weight_bytes(cout, cin, dtype);
+    if (!need || !w || !wp || !aligned16(wp) || wp_bytes < need) {
+        set_error("pack_weight: bad arguments (cout=%d cin=%d dtype=%d bytes=%zu need=%zu)", cout, cin, dtype,
+                  wp_bytes, need);
+        return SR355_ERR_INVALID;
+    }
+    return launch_pack_weight(w, bias, cout, cin, dtype, wp, bp, (hipStream_t)stream);
+}
+
+int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
+    if (!p) {
+        set_error("conv3x3_fwd: args is null");
+        return SR355_ERR_INVALID;
+    }
+    const int cpu = unit_channels(p->dtype);
+    if (cpu < 0) {
+        set_error("conv3x3_fwd: unknown dtype %d", p->dtype);
+        return SR355_ERR_INVALID;
+    }
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || (p->upsample != 0 && p->upsample != 1)) {
+        set_error("conv3x3_fwd: bad shape N=%d H=%d W=%d cout=%d upsample=%d", p->N, p->H, p->W, p->cout,
+                  p->upsample);
+        return SR355_ERR_INVALID;
+    }
+    if (p->upsample && ((p->H | p->W) & 1)) {
+        set_error("conv3x3_fwd: fused x2 upsample needs even output H, W (got %d x %d)", p->H, p->W);
+        return SR355_ERR_INVALID;
+    }
+    const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
+    if (p->cin_units < 2 || (p->cin_units & 1) || p->cin_units > p->in_units) {
+        set_error("conv3x3_fwd: cin_units=%d must be even and within in_units=%d", p->cin_units, p->in_units);
+        return SR355_ERR_INVALID;
+    }
+    const size_t img_bytes = (size_t)Hin * p->in_units * Win * 16;
+    if (img_bytes >= ((size_t)1 << 31)) {
+        set_error("conv3x3_fwd: one input image is %zu bytes; the kernel indexes an image with 31 bits",
+                  img_bytes);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    if (!p->in_dev || !aligned16(p->in_dev) || p->in_bytes < img_bytes * p->N) {
+        set_error("conv3x3_fwd: input buffer missing, misaligned or too small (%zu < %zu)", p->in_bytes,
+                  img_bytes * p->N);
+        return SR355_ERR_INVALID;
+    }
+    const int cout_pad = cout_pad_for(p->cout);
+    if (!p->w_packed_dev || !aligned16(p->w_packed_dev) || !p->bias_packed_dev || !aligned16(p->bias_packed_dev) ||
+        p->w_packed_bytes < (size_t)p->cin_units * 9 * cout_pad * 16) {
+        set_error("conv3x3_fwd: packed weights/bias missing, misaligned or too small");
+        return SR355_ERR_INVALID;
+    }
+    if (!p->out_act_dev && !p->out_f32_dev && !p->out_nchw_dev) {
+        set_error("conv3x3_fwd: no output requested");
+        return SR355_ERR_INVALID;
+    }
+    const bool trunk = p->res1_dev || p->res2_dev || p->out_f32_dev;
+    if ((trunk || p->out_act_dev) && (p->cout & 3)) {
+        set_error("conv3x3_fwd: cout=%d must be a multiple of 4 for blocked outputs / residuals", p->cout);
+        return SR355_ERR_INVALID;
+    }
+    if (trunk) {
+        const size_t need = (size_t)p->N * p->H * p->W * p->cout * 4;
+        if (p->res_bytes < need || !aligned16(p->res1_dev) || !aligned16(p->res2_dev) ||
+            !aligned16(p->out_f32_dev)) {
+            set_error("conv3x3_fwd: residual / fp32 output tensors misaligned or too small (%zu < %zu)",
+                      p->res_bytes, need);
+            return SR355_ERR_INVALID;
+        }
+    }
+    if (p->out_act_dev) {
+        const int units = (p->cout + cpu - 1) / cpu;
+        const size_t need = (size_t)p->N * p->H * p->out_units * p->W * 16;
+        if (p->out_unit_off < 0 || p->out_unit_off + units > p->out_units || !aligned16(p->out_act_dev) ||
+            p->out_act_bytes < need) {
+            set_error("conv3x3_fwd: activation output geometry invalid (off=%d units=%d of %d, %zu < %zu bytes)",
+                      p->out_unit_off, units, p->out_units, p->out_act_bytes, need);
+            return SR355_ERR_INVALID;
+        }
+    }
+    if (p->out_nchw_dev && p->out_nchw_bytes < (size_t)p->N * p->cout * p->H * p->W * 4) {
+        set_error("conv3x3_fwd: NCHW output too small");
+        return SR355_ERR_INVALID;
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const unsigned char *)p->in_dev;
+    a.w = (const unsigned char *)p->w_packed_dev;
+    a.bias = p->bias_packed_dev;
+    a.out_act = (unsigned char *)p->out_act_dev;
+    a.out_f32 = p->out_f32_dev;
+    a.out_nchw = p->out_nchw_dev;
+    a.res1 = p->res1_dev;
+    a.res2 = p->res2_dev;
+    a.res1_scale = p->res1_scale;
+    a.res2_scale = p->res2_scale;
+    a.slope = p->lrelu_slope;
+    a.N = p->N;
+    a.H = p->H;
+    a.W = p->W;
+    a.in_units = p->in_units;
+    a.ups = p->upsample;
+    a.out_units = p->out_units;
+    a.out_unit_off = p->out_unit_off;
+    a.cout_real = p->cout;
+    a.cout_pad = cout_pad;
+    a.f32_units = p->cout / 4;
+    return launch_conv3x3(a, p->dtype, p->cin_units, (hipStream_t)stream);
+}
+
+// ---- generator ----------------------------------------------------------------------------
+int sr355_generator_num_convs(const sr355_generator_cfg *cfg) {
+    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
+    return 1 + 15 * cfg->num_blocks + 5;
+}
+
+size_t sr355_generator_packed_bytes(const sr355_generator_cfg *cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    size_t total = 0;
+    conv_specs(*cfg, &total);
+    return total;
+}
+
+int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_ptrs, const float *const *b_ptrs,
+                         int n_convs, void *packed, size_t packed_bytes, void *stream) {
+    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
+    size_t total = 0;
+    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
+    if (!w_ptrs || !b_ptrs || n_convs != (int)specs.size() || !packed || !aligned16(packed) ||
+        packed_bytes < total) {
+        set_error("generator_pack: need %zu conv tensors and %zu bytes (got %d, %zu)", specs.size(), total,
+                  n_convs, packed_bytes);
+        return SR355_ERR_INVALID;
+    }
+    unsigned char *base = (unsigned char *)packed;
+    for (size_t i = 0; i < specs.size(); ++i) {
+        if (!w_ptrs[i] || !b_ptrs[i]) {
+            set_error("generator_pack: tensor %zu is null", i);
+            return SR355_ERR_INVALID;
+        }
+        int rc = launch_pack_weight(w_ptrs[i], b_ptrs[i], specs[i].cout, specs[i].cin, cfg->dtype,
+                                    base + specs[i].w_off, (float *)(base + specs[i].b_off), (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SR355_OK;
+}
+
+size_t sr355_generator_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    if (!cfg_ok(cfg) || N < 1 || H < 1 || W < 1) return 0;
+    return carve(*cfg, N, H, W).total;
+}
+
+int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
+                            const float *in_nchw, float *out_nchw, int N, int H, int W, void *workspace,
+                            size_t workspace_bytes, void *stream_) {
+    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t total = 0;
+    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
+    if (N < 1 || H < 1 || W < 1 || !packed || !aligned16(packed) || packed_bytes < total || !in_nchw ||
+        !out_nchw) {
+        set_error("generator_forward: bad arguments (N=%d H=%d W=%d packed %zu of %zu bytes)", N, H, W,
+                  packed_bytes, total);
+        return SR355_ERR_INVALID;
+    }
+    const Workspace ws = carve(*cfg, N, H, W);
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < ws.total) {
+        set_error("generator_forward: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", ws.total,
+                  workspace_bytes);
+        return SR355_ERR_INVALID;
+    }
+    if ((size_t)16 * H * W * ws.nf_units * 16 >= ((size_t)1 << 31)) {
+        set_error("generator_forward: %dx%d input makes one HR feature map exceed 2 GiB; tile the image", H, W);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    const int dtype = cfg->dtype, cpu = unit_channels(dtype);
+    const int nf = cfg->num_features, gc = cfg->growth_channels;
+    unsigned char *wsb = (unsigned char *)workspace;
+    const unsigned char *pk = (const unsigned char *)packed;
+    float *T = (float *)(wsb + ws.T), *R = (float *)(wsb + ws.R), *F = (float *)(wsb + ws.F);
+
+    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, wsb + ws.x0, ws.in_units, stream);
+    if (rc) return rc;
+
+    size_t ci = 0;  // running conv index
+    auto conv = [&](const unsigned char *in, int in_units, int cin_units, int h, int w, int ups,
+                    unsigned char *out_act, int out_units, int out_off, float slope, const float *res1, float s1,
+                    const float *res2, float s2, float *out_f32, float *out_nc) -> int {
+        const ConvSpec &sp = specs[ci++];
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in;
+        a.w = pk + sp.w_off;
+        a.bias = (const float *)(pk + sp.b_off);
+        a.out_act = out_act;
+        a.out_f32 = out_f32;
+        a.out_nchw = out_nc;
+        a.res1 = res1;
+        a.res2 = res2;
+        a.res1_scale = s1;
+        a.res2_scale = s2;
+        a.slope = slope;
+        a.N = N;
+        a.H = h;
+        a.W = w;
+        a.in_units = in_units;
+        a.ups = ups;
+        a.out_units = out_units;
+        a.out_unit_off = out_off;
+        a.cout_real = sp.cout;
+        a.cout_pad = cout_pad_for(sp.cout);
+        a.f32_units = sp.cout / 4;
+        return launch_conv3x3(a, dtype, cin_units, stream);
+    };
+
+    unsigned char *cur = wsb + ws.bufA, *nxt = wsb + ws.bufB;
+    // conv_first (:56): x -> block buffer units [0, nf) and the fp32 copy F kept for the global skip.
+    if ((rc = conv(wsb + ws.x0, ws.in_units, ws.in_units, H, W, 0, cur, ws.blk_units, 0, 1.f, nullptr, 0.f,
+                   nullptr, 0.f, F, nullptr)))
+        return rc;
+    for (int b = 0; b < cfg->num_blocks; ++b) {
+        const float *rrdb_in = (b == 0) ? F : R;  // fp32 input of this RRDB (:35)
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 4; ++k) {  // growth convs (:19-22): read [0, nf+k*gc), append gc channels
+                if ((rc = conv(cur, ws.blk_units, (nf + k * gc) / cpu, H, W, 0, cur, ws.blk_units,
+                               (nf + k * gc) / cpu, 0.2f, nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+                    return rc;
+            }
+            // conv5 + dense skip (:23-24); the third block also folds the RRDB skip (:39).
+            const float *res1 = (r == 0) ? rrdb_in : T;
+            if (r < 2)
+                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f,
+                          nullptr, 0.f, T, nullptr);
+            else
+                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f,
+                          rrdb_in, 0.2f, R, nullptr);
+            if (rc) return rc;
+            unsigned char *t = cur;
+            cur = nxt;
+            nxt = t;
+        }
+    }
+    // trunk_conv + global skip (:57-58)
+    if ((rc = conv(cur, ws.blk_units, ws.nf_units, H, W, 0, wsb + ws.L1, ws.nf_units, 0, 1.f, F, 1.f, nullptr,
+                   0.f, nullptr, nullptr)))
+        return rc;
+    // nearest x2 + upconv1 + lrelu (:59), nearest x2 + upconv2 + lrelu (:60)
+    if ((rc = conv(wsb + ws.L1, ws.nf_units, ws.nf_units, 2 * H, 2 * W, 1, wsb + ws.H1, ws.nf_units, 0, 0.2f,
+                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+        return rc;
+    if ((rc = conv(wsb + ws.H1, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 1, wsb + ws.H2, ws.nf_units, 0, 0.2f,
+                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+        return rc;
+    // HR_conv + lrelu, conv_last (:61)
+    if ((rc = conv(wsb + ws.H2, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, wsb + ws.H3, ws.nf_units, 0, 0.2f,
+                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+        return rc;
+    if ((rc = conv(wsb + ws.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f,
+                   nullptr, 0.f, nullptr, out_nchw)))
+        return rc;
+    return SR355_OK;
+}
+
+}  // extern "C"

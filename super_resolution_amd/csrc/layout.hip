@@ -1,0 +1,127 @@
+// Layout conversion at the module boundary and weight packing.
+//
+// The reference keeps NCHW fp32 activations and OIHW fp32 weights everywhere
+// (/root/reference/esrgan/models/esrgan_model.py:10-14, :55-62).  The kernels here move
+// between that and the blocked activation layout [N][H][U][W][16 B] and the packed weight
+// layout [cin_units][9][cout_pad][16 B] consumed by the MFMA convolution.
+#include "sr355_internal.h"
+
+namespace sr355 {
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// One thread per (n, y, unit, x): gathers CPU channels from NCHW and writes one 16-byte unit.
+template <typename T>
+__global__ void nchw_to_blocked_kernel(const float *__restrict__ src, T *__restrict__ dst, int N, int C,
+                                       int H, int W, int U) {
+    constexpr int CPU = 16 / sizeof(T);
+    const size_t total = (size_t)N * H * U * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t t = i / W;
+        const int u = (int)(t % U);
+        t /= U;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        T v[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) {
+            const int c = u * CPU + e;
+            v[e] = from_f32<T>(c < C ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f);
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(dst)[i] = pk;
+    }
+}
+
+// One thread per (n, c, y, x) of the NCHW destination.
+template <typename T>
+__global__ void blocked_to_nchw_kernel(const T *__restrict__ src, float *__restrict__ dst, int N, int C,
+                                       int H, int W, int U, int unit_off) {
+    constexpr int CPU = 16 / sizeof(T);
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t t = i / W;
+        const int y = (int)(t % H);
+        t /= H;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        const int u = unit_off + c / CPU, e = c % CPU;
+        dst[i] = (float)src[((((size_t)n * H + y) * U + u) * W + x) * CPU + e];
+    }
+}
+
+// One thread per packed unit (u, tap, co): CPU input channels of one output channel and tap.
+template <typename T>
+__global__ void pack_weight_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                   T *__restrict__ wp, float *__restrict__ bp, int cout, int cin,
+                                   int cin_units, int cout_pad) {
+    constexpr int CPU = 16 / sizeof(T);
+    const int total = cin_units * 9 * cout_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % cout_pad;
+        const int t = i / cout_pad;
+        const int tap = t % 9;
+        const int u = t / 9;
+        T v[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) {
+            const int ci = u * CPU + e;
+            v[e] = from_f32<T>((co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f);
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(wp)[i] = pk;
+        if (i < cout_pad && bp) bp[i] = (i < cout && bias) ? bias[i] : 0.f;
+    }
+}
+
+static unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
+                           int dst_units, hipStream_t stream) {
+    const size_t total = (size_t)N * H * dst_units * W;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(nchw_to_blocked_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, src,
+                           (__bf16 *)dst, N, C, H, W, dst_units);
+    else
+        hipLaunchKernelGGL(nchw_to_blocked_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src,
+                           (float *)dst, N, C, H, W, dst_units);
+    return check_hip(hipGetLastError(), "nchw_to_blocked launch");
+}
+
+int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C, int H,
+                           int W, float *dst, hipStream_t stream) {
+    const size_t total = (size_t)N * C * H * W;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(blocked_to_nchw_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const __bf16 *)src, dst, N, C, H, W, src_units, unit_off);
+    else
+        hipLaunchKernelGGL(blocked_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const float *)src, dst, N, C, H, W, src_units, unit_off);
+    return check_hip(hipGetLastError(), "blocked_to_nchw launch");
+}
+
+int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp,
+                       float *bp, hipStream_t stream) {
+    const int cu = cin_units_for(cin, dtype), cp = cout_pad_for(cout);
+    const size_t total = (size_t)cu * 9 * cp;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, w, bias,
+                           (__bf16 *)wp, bp, cout, cin, cu, cp);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, bias,
+                           (float *)wp, bp, cout, cin, cu, cp);
+    return check_hip(hipGetLastError(), "pack_weight launch");
+}
+
+}  // namespace sr355

@@ -1,0 +1,52 @@
+// Internal declarations shared by the translation units of libsr355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sr355.h"
+
+namespace sr355 {
+
+// Arguments of one conv3x3 launch, passed by value to the kernel.
+struct ConvArgs {
+    const unsigned char *in;     // blocked activations
+    const unsigned char *w;      // packed weights [cin_units][9][cout_pad][16 B]
+    const float *bias;           // [cout_pad]
+    unsigned char *out_act;      // blocked, may be null
+    float *out_f32;              // fp32 trunk [N][H][f32_units][W][4], may be null
+    float *out_nchw;             // [N][cout_real][H][W], may be null
+    const float *res1;           // fp32 trunk, may be null
+    const float *res2;           // fp32 trunk, may be null
+    float res1_scale, res2_scale;
+    float slope;                 // LeakyReLU slope, 1.0f = identity
+    int N, H, W;                 // output dims
+    int in_units;                // units per pixel of the input buffer
+    int n_stages;                // cin_units / SU
+    int ups;                     // 0 | 1
+    int out_units, out_unit_off; // geometry of out_act
+    int cout_real, cout_pad;
+    int f32_units;               // units per pixel of the fp32 trunk tensors (cout_real / 4)
+    int tiles_x, tiles_y;
+};
+
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+// Launch the MFMA conv.  cin_units must be even; returns SR355_* code.
+int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, hipStream_t stream);
+
+int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
+                           int dst_units, hipStream_t stream);
+int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C,
+                           int H, int W, float *dst, hipStream_t stream);
+int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp,
+                       float *bp, hipStream_t stream);
+
+inline int unit_channels(int dtype) { return dtype == SR355_DTYPE_BF16 ? 8 : dtype == SR355_DTYPE_F32 ? 4 : -1; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int cin_units_for(int cin, int dtype) { return round_up((cin + unit_channels(dtype) - 1) / unit_channels(dtype), 2); }
+inline int cout_pad_for(int cout) { return round_up(cout, 32); }
+
+}  // namespace sr355

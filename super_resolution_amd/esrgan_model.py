@@ -1,0 +1,208 @@
+"""Drop-in for the reference's ``esrgan/models/esrgan_model.py`` generator classes.
+
+Same class names, constructor arguments, parameter names / shapes / init order (so the same
+``torch.manual_seed`` gives the same weights and ``state_dict`` files interchange), same
+call sites (``netG(lr)``, ``.clamp(0,1)``, ``nn.DataParallel``-prefixed checkpoints).  The
+parameters stay fp32 OIHW ``nn.Conv2d`` tensors; the arithmetic runs in libsr355.so:
+
+* ``GeneratorRRDB.forward``  -> one ``sr355::generator_forward`` call (351 fused conv launches)
+  replacing /root/reference/esrgan/models/esrgan_model.py:55-62
+* ``ResidualDenseBlock`` / ``RRDB`` forward -> ``sr355::conv3x3_fwd`` per conv, writing at channel
+  offsets of one blocked buffer, replacing :18-24 and :35-39
+
+There is no CPU path: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from ._lib import DTYPE_BF16, DTYPE_F32
+
+_PRECISIONS = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32, "f32": DTYPE_F32}
+_SLOPE = 0.2
+_RES = 0.2
+
+
+def _conv(cin: int, cout: int) -> nn.Conv2d:
+    # Parameter container with the reference's default initialisation (nn.Conv2d k=3, s=1, p=1).
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1)
+
+
+class _PackCache:
+    """Packed copies of a module's conv parameters, rebuilt when any parameter changes."""
+
+    def __init__(self) -> None:
+        self.key = None
+        self.value = None
+
+    def get(self, params: List[Tensor], dtype: int, builder):
+        key = (dtype, params[0].device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        if key != self.key:
+            self.value = builder()
+            self.key = key
+        return self.value
+
+
+class ResidualDenseBlock(nn.Module):
+    """Five 3x3 convs over a growing channel stack; ``x + 0.2 * conv5(...)``."""
+
+    def __init__(self, in_channels: int = 64, growth_channels: int = 32, *, precision: str = "bf16"):
+        super().__init__()
+        self.in_channels, self.growth_channels = in_channels, growth_channels
+        for k in range(5):
+            setattr(self, f"conv{k + 1}",
+                    _conv(in_channels + k * growth_channels, growth_channels if k < 4 else in_channels))
+        self.res_scale = _RES
+        self.precision = precision
+        self._cache = _PackCache()
+
+    def _convs(self) -> List[nn.Conv2d]:
+        return [getattr(self, f"conv{k}") for k in range(1, 6)]
+
+    def _packed(self, dtype: int):
+        params = [p for c in self._convs() for p in (c.weight, c.bias)]
+        return self._cache.get(params, dtype, lambda: [ops.pack_weight(c.weight.detach(), c.bias.detach(), dtype)
+                                                        for c in self._convs()])
+
+    def _run(self, buf: Tensor, trunk_in: Tensor, trunk_out: Tensor, nxt: Tensor, dtype: int,
+             outer: Optional[Tensor] = None, outer_out: Optional[Tensor] = None) -> None:
+        """``buf`` holds x in units [0, nf); growth outputs are appended in place; conv5 writes
+        ``trunk_in + 0.2*conv5`` (optionally folded into ``outer + 0.2*(...)``) to the fp32 trunk
+        and to units [0, nf) of ``nxt``."""
+        cpu = ops.UNIT_CHANNELS[dtype]
+        nf, gc = self.in_channels, self.growth_channels
+        packed = self._packed(dtype)
+        for k in range(4):
+            wp, bp = packed[k]
+            ops.conv3x3_fwd(buf, (nf + k * gc) // cpu, wp, bp, gc, _SLOPE, 0, None, 0.0, None, 0.0,
+                            buf, (nf + k * gc) // cpu, None, None)
+        wp, bp = packed[4]
+        if outer is None:
+            ops.conv3x3_fwd(buf, (nf + 4 * gc) // cpu, wp, bp, nf, 1.0, 0, trunk_in, self.res_scale, None, 0.0,
+                            nxt, 0, trunk_out, None)
+        else:
+            ops.conv3x3_fwd(buf, (nf + 4 * gc) // cpu, wp, bp, nf, 1.0, 0, trunk_in, self.res_scale, outer, _RES,
+                            nxt, 0, outer_out, None)
+
+    def forward(self, x: Tensor) -> Tensor:
+        _check_input(x, self.in_channels)
+        _no_grad_only(self, x)
+        dtype = _PRECISIONS[self.precision]
+        cpu = ops.UNIT_CHANNELS[dtype]
+        units = (self.in_channels + 4 * self.growth_channels) // cpu
+        buf = ops.to_blocked(x, units, dtype)
+        nxt = torch.empty_like(buf)
+        trunk = ops.to_blocked(x, self.in_channels // 4, DTYPE_F32)
+        self._run(buf, trunk, trunk, nxt, dtype)
+        return ops.from_blocked(trunk, 0, self.in_channels)
+
+
+class RRDB(nn.Module):
+    """Three dense blocks and the outer ``x + 0.2 * out`` skip."""
+
+    def __init__(self, in_channels: int, growth_channels: int, *, precision: str = "bf16"):
+        super().__init__()
+        self.in_channels, self.growth_channels = in_channels, growth_channels
+        for r in (1, 2, 3):
+            setattr(self, f"rdb{r}", ResidualDenseBlock(in_channels, growth_channels, precision=precision))
+        self.res_scale = _RES
+        self.precision = precision
+
+    def forward(self, x: Tensor) -> Tensor:
+        _check_input(x, self.in_channels)
+        _no_grad_only(self, x)
+        dtype = _PRECISIONS[self.precision]
+        cpu = ops.UNIT_CHANNELS[dtype]
+        units = (self.in_channels + 4 * self.growth_channels) // cpu
+        cur = ops.to_blocked(x, units, dtype)
+        nxt = torch.empty_like(cur)
+        outer = ops.to_blocked(x, self.in_channels // 4, DTYPE_F32)   # fp32 RRDB input
+        trunk = torch.empty_like(outer)
+        self.rdb1._run(cur, outer, trunk, nxt, dtype)
+        self.rdb2._run(nxt, trunk, trunk, cur, dtype)
+        self.rdb3._run(cur, trunk, None, nxt, dtype, outer=outer, outer_out=outer)
+        return ops.from_blocked(outer, 0, self.in_channels)
+
+
+class GeneratorRRDB(nn.Module):
+    """ESRGAN x4 generator.  ``precision`` selects the kernel arithmetic: ``"bf16"`` (bf16 storage,
+    fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, num_features: int = 64,
+                 num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16"):
+        super().__init__()
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_features, self.num_blocks, self.growth_channels = num_features, num_blocks, growth_channels
+        self.precision = precision
+        self.conv_first = _conv(in_channels, num_features)
+        self.body = nn.Sequential(*[RRDB(num_features, growth_channels, precision=precision)
+                                    for _ in range(num_blocks)])
+        for name in ("trunk_conv", "upconv1", "upconv2", "HR_conv"):
+            setattr(self, name, _conv(num_features, num_features))
+        self.conv_last = _conv(num_features, out_channels)
+        self._cache = _PackCache()
+        self._workspace: Optional[Tensor] = None
+
+    # -- parameter plumbing ---------------------------------------------------------------
+    def conv_modules(self) -> List[nn.Conv2d]:
+        """The convs in state_dict order."""
+        mods = [self.conv_first]
+        for rrdb in self.body:
+            for r in (1, 2, 3):
+                mods.extend(getattr(rrdb, f"rdb{r}")._convs())
+        mods += [self.trunk_conv, self.upconv1, self.upconv2, self.HR_conv, self.conv_last]
+        return mods
+
+    def cfg(self) -> List[int]:
+        return [self.in_channels, self.out_channels, self.num_features, self.num_blocks,
+                self.growth_channels, _PRECISIONS[self.precision]]
+
+    def packed_parameters(self) -> Tensor:
+        convs = self.conv_modules()
+        params = [p for c in convs for p in (c.weight, c.bias)]
+        cfg = self.cfg()
+        return self._cache.get(params, cfg[5], lambda: ops.generator_pack(
+            [c.weight.detach() for c in convs], [c.bias.detach() for c in convs], cfg))
+
+    def workspace(self, N: int, H: int, W: int, device) -> Tensor:
+        need = ops.generator_workspace_bytes(self.cfg(), N, H, W)
+        ws = self._workspace
+        if ws is None or ws.numel() < need or ws.device != device:
+            self._workspace = None          # release before growing
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # -- forward --------------------------------------------------------------------------
+    def forward(self, x: Tensor) -> Tensor:
+        _check_input(x, self.in_channels)
+        _no_grad_only(self, x)
+        xin = x.detach().float().contiguous()
+        N, _c, H, W = xin.shape
+        return ops.generator_forward(xin, self.packed_parameters(), self.workspace(N, H, W, xin.device), self.cfg())
+
+
+# RRDBNet is the name BasicSR-derived code uses for the same network.
+RRDBNet = GeneratorRRDB
+
+
+def _check_input(x: Tensor, channels: int) -> None:
+    if x.dim() != 4 or x.shape[1] != channels:
+        raise RuntimeError(f"expected an NCHW tensor with {channels} channels, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("super_resolution_amd runs on ROCm devices only: move the module and its input to "
+                           "'cuda' (there is no CPU fallback)")
+
+
+def _no_grad_only(module: nn.Module, x: Tensor) -> None:
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
+        raise NotImplementedError(
+            "the HIP backward (dgrad/wgrad) kernels are not wired yet: call under torch.no_grad() "
+            "or with requires_grad_(False) parameters")

@@ -1,0 +1,228 @@
+"""``torch.library`` custom ops (namespace ``sr355``) over the C ABI of libsr355.so.
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic runs in the
+HIP kernels.  Blocked activation tensors have shape ``[N, H, U, W, c]`` with ``c`` = 8
+(bf16) or 4 (fp32) channels per 16-byte unit; fp32 trunk tensors are ``[N, H, C/4, W, 4]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, GeneratorCfg, check
+
+_TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
+_CODE = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}
+UNIT_CHANNELS = {DTYPE_BF16: 8, DTYPE_F32: 4}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("sr355 ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError("sr355 ops need contiguous tensors")
+
+
+def _nbytes(t: Optional[Tensor]) -> int:
+    return 0 if t is None else t.numel() * t.element_size()
+
+
+# ------------------------------------------------------------------------------------
+@torch.library.custom_op("sr355::to_blocked", mutates_args=())
+def to_blocked(x: Tensor, units: int, dtype: int) -> Tensor:
+    """NCHW fp32 -> blocked [N,H,units,W,c]; channels beyond C are zero."""
+    _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("to_blocked expects an fp32 NCHW tensor")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, H, units, W, UNIT_CHANNELS[dtype]), dtype=_TORCH_DTYPE[dtype], device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().sr355_nchw_to_blocked(x.data_ptr(), N, Cc, H, W, dtype, out.data_ptr(), units,
+                                               _nbytes(out), _stream()), "sr355_nchw_to_blocked")
+    return out
+
+
+@to_blocked.register_fake
+def _(x, units, dtype):
+    N, _c, H, W = x.shape
+    return x.new_empty((N, H, units, W, UNIT_CHANNELS[dtype]), dtype=_TORCH_DTYPE[dtype])
+
+
+@torch.library.custom_op("sr355::from_blocked", mutates_args=())
+def from_blocked(buf: Tensor, unit_off: int, channels: int) -> Tensor:
+    """Blocked units [unit_off, ...) -> NCHW fp32 with ``channels`` channels."""
+    _need_cuda(buf)
+    N, H, U, W, _c = buf.shape
+    out = torch.empty((N, channels, H, W), dtype=torch.float32, device=buf.device)
+    with torch.cuda.device(buf.device):
+        check(_lib.lib().sr355_blocked_to_nchw(buf.data_ptr(), U, unit_off, _CODE[buf.dtype], N, channels, H, W,
+                                               out.data_ptr(), _nbytes(out), _stream()), "sr355_blocked_to_nchw")
+    return out
+
+
+@from_blocked.register_fake
+def _(buf, unit_off, channels):
+    N, H, _u, W, _c = buf.shape
+    return buf.new_empty((N, channels, H, W), dtype=torch.float32)
+
+
+@torch.library.custom_op("sr355::pack_weight", mutates_args=())
+def pack_weight(w: Tensor, bias: Tensor, dtype: int) -> Tuple[Tensor, Tensor]:
+    """OIHW fp32 weight + bias -> (packed weight bytes, zero-padded fp32 bias)."""
+    _need_cuda(w, bias)
+    if w.dtype != torch.float32 or w.dim() != 4 or w.shape[2:] != (3, 3):
+        raise RuntimeError("pack_weight expects an fp32 [cout, cin, 3, 3] tensor")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    L = _lib.lib()
+    nbytes = L.sr355_packed_weight_bytes(cout, cin, dtype)
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        check(L.sr355_pack_weight(w.data_ptr(), bias.data_ptr(), cout, cin, dtype, wp.data_ptr(), nbytes,
+                                  bp.data_ptr(), _stream()), "sr355_pack_weight")
+    return wp, bp
+
+
+@pack_weight.register_fake
+def _(w, bias, dtype):
+    cout, cin = w.shape[0], w.shape[1]
+    cpu = UNIT_CHANNELS[dtype]
+    cu = ((cin + cpu - 1) // cpu + 1) // 2 * 2
+    cp = (cout + 31) // 32 * 32
+    return (w.new_empty(cu * 9 * cp * 16, dtype=torch.uint8), w.new_empty(cp, dtype=torch.float32))
+
+
+@torch.library.custom_op("sr355::conv3x3_fwd", mutates_args=("out_act", "out_f32", "out_nchw"))
+def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Tensor, cout: int,
+                lrelu_slope: float, upsample: int,
+                res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
+                out_act: Optional[Tensor], out_unit_off: int,
+                out_f32: Optional[Tensor], out_nchw: Optional[Tensor]) -> None:
+    """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, scaled
+    skips and optional nearest-x2 upsample of the input; writes any subset of the three outputs."""
+    _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw)
+    a = ConvArgs()
+    a.dtype = _CODE[in_buf.dtype]
+    if out_act is not None:
+        N, H, _U, W, _c = out_act.shape
+    elif out_f32 is not None:
+        N, H, _U, W, _c = out_f32.shape
+    elif out_nchw is not None:
+        N, _cc, H, W = out_nchw.shape
+    else:
+        raise RuntimeError("conv3x3_fwd: no output tensor given")
+    a.N, a.H, a.W, a.upsample = int(N), int(H), int(W), int(upsample)
+    a.in_dev, a.in_bytes = in_buf.data_ptr(), _nbytes(in_buf)
+    a.in_units, a.cin_units = int(in_buf.shape[2]), int(cin_units)
+    if in_buf.shape[0] != N or in_buf.shape[1] != (H >> upsample) or in_buf.shape[3] != (W >> upsample):
+        raise RuntimeError(f"conv3x3_fwd: input {tuple(in_buf.shape)} does not match output N={N} H={H} W={W} "
+                           f"upsample={upsample}")
+    a.w_packed_dev, a.w_packed_bytes = w_packed.data_ptr(), _nbytes(w_packed)
+    a.bias_packed_dev = bias_packed.data_ptr()
+    a.cout, a.lrelu_slope = int(cout), float(lrelu_slope)
+    a.res1_dev, a.res1_scale = _ptr(res1), float(res1_scale)
+    a.res2_dev, a.res2_scale = _ptr(res2), float(res2_scale)
+    sizes = [_nbytes(t) for t in (res1, res2, out_f32) if t is not None]
+    a.res_bytes = min(sizes) if sizes else 0
+    a.out_act_dev, a.out_act_bytes = _ptr(out_act), _nbytes(out_act)
+    a.out_units = int(out_act.shape[2]) if out_act is not None else 0
+    a.out_unit_off = int(out_unit_off)
+    a.out_f32_dev = _ptr(out_f32)
+    a.out_nchw_dev, a.out_nchw_bytes = _ptr(out_nchw), _nbytes(out_nchw)
+    with torch.cuda.device(in_buf.device):
+        check(_lib.lib().sr355_conv3x3_fwd(C.byref(a), _stream()), "sr355_conv3x3_fwd")
+
+
+@conv3x3_fwd.register_fake
+def _(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale, res2, res2_scale,
+      out_act, out_unit_off, out_f32, out_nchw):
+    return None
+
+
+# ------------------------------------------------------------------------------------
+def make_cfg(cfg: List[int]) -> GeneratorCfg:
+    """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype]."""
+    c = GeneratorCfg()
+    (c.in_channels, c.out_channels, c.num_features, c.num_blocks, c.growth_channels, c.dtype) = [int(v) for v in cfg]
+    c.trunk_fp32 = 1
+    return c
+
+
+def generator_packed_bytes(cfg: List[int]) -> int:
+    c = make_cfg(cfg)
+    n = _lib.lib().sr355_generator_packed_bytes(C.byref(c))
+    if n == 0:
+        check(-1, "sr355_generator_packed_bytes")
+    return n
+
+
+def generator_workspace_bytes(cfg: List[int], N: int, H: int, W: int) -> int:
+    c = make_cfg(cfg)
+    n = _lib.lib().sr355_generator_workspace_bytes(C.byref(c), N, H, W)
+    if n == 0:
+        check(-1, "sr355_generator_workspace_bytes")
+    return n
+
+
+@torch.library.custom_op("sr355::generator_pack", mutates_args=())
+def generator_pack(weights: List[Tensor], biases: List[Tensor], cfg: List[int]) -> Tensor:
+    """Pack all conv parameters (state_dict order) into one device blob."""
+    _need_cuda(*weights, *biases)
+    c = make_cfg(cfg)
+    L = _lib.lib()
+    n = len(weights)
+    nbytes = generator_packed_bytes(cfg)
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=weights[0].device)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in biases])
+    for w in weights + biases:
+        if w.dtype != torch.float32:
+            raise RuntimeError("generator_pack expects fp32 parameters")
+    with torch.cuda.device(blob.device):
+        check(L.sr355_generator_pack(C.byref(c), wp, bp, n, blob.data_ptr(), nbytes, _stream()),
+              "sr355_generator_pack")
+    return blob
+
+
+@generator_pack.register_fake
+def _(weights, biases, cfg):
+    return weights[0].new_empty(generator_packed_bytes(cfg), dtype=torch.uint8)
+
+
+@torch.library.custom_op("sr355::generator_forward", mutates_args=("workspace",))
+def generator_forward(x: Tensor, packed: Tensor, workspace: Tensor, cfg: List[int]) -> Tensor:
+    """GeneratorRRDB.forward: [N,in,H,W] fp32 -> [N,out,4H,4W] fp32, unclamped."""
+    _need_cuda(x, packed, workspace)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("generator_forward expects an fp32 NCHW tensor")
+    c = make_cfg(cfg)
+    N, Cin, H, W = (int(v) for v in x.shape)
+    if Cin != c.in_channels:
+        raise RuntimeError(f"generator_forward: input has {Cin} channels, model expects {c.in_channels}")
+    out = torch.empty((N, c.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().sr355_generator_forward(C.byref(c), packed.data_ptr(), _nbytes(packed), x.data_ptr(),
+                                                 out.data_ptr(), N, H, W, workspace.data_ptr(),
+                                                 _nbytes(workspace), _stream()), "sr355_generator_forward")
+    return out
+
+
+@generator_forward.register_fake
+def _(x, packed, workspace, cfg):
+    N, _c, H, W = x.shape
+    return x.new_empty((N, cfg[1], 4 * H, 4 * W), dtype=torch.float32)

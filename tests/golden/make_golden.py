@@ -1,0 +1,170 @@
+"""Generate tests/golden/*.npz by running the REFERENCE classes on seeded inputs.
+
+Runs only in the build container (needs /root/reference); the outputs are committed.
+The reference module imports torchvision at top level (esrgan_model.py:4) although the
+generator and discriminator use only torch.nn, so an empty ``torchvision.models`` module
+is placed in sys.modules before loading the file by path.  Nothing of the reference's
+text is stored: fixtures hold seeds, inputs, outputs and gradients only.
+
+    cd /tmp && python /root/repo/tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/esrgan/models/esrgan_model.py"
+
+
+def load_reference():
+    for m in ("torchvision", "torchvision.models"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    spec = importlib.util.spec_from_file_location("ref_esrgan_model", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def summarize(t: torch.Tensor, stride: int = 97):
+    """A gradient tensor as (strided sample, float64 sum, float64 abs-sum)."""
+    flat = t.detach().reshape(-1)
+    return (flat[::stride].numpy().copy(),
+            np.float64(flat.double().sum().item()),
+            np.float64(flat.double().abs().sum().item()))
+
+
+def put_grads(store: dict, module: torch.nn.Module, full=()):
+    for name, p in module.named_parameters():
+        s, a, b = summarize(p.grad)
+        store[f"gs/{name}"] = s
+        store[f"gsum/{name}"] = a
+        store[f"gabs/{name}"] = b
+        if name in full:
+            store[f"gfull/{name}"] = p.grad.detach().numpy().copy()
+
+
+def weight_sums(store: dict, module: torch.nn.Module):
+    for name, p in module.state_dict().items():
+        if p.dtype.is_floating_point:
+            store[f"wsum/{name}"] = np.float64(p.double().sum().item())
+
+
+def main():
+    ref = load_reference()
+    torch.set_num_threads(8)
+
+    # G1: one dense block ---------------------------------------------------------
+    torch.manual_seed(0)
+    rdb = ref.ResidualDenseBlock(64, 32)
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(1, 64, 8, 8, generator=g).requires_grad_(True)
+    r = torch.randn(1, 64, 8, 8, generator=g)
+    out = rdb(x)
+    (out * r).sum().backward()
+    st = {"seed": 0, "x": x.detach().numpy(), "r": r.numpy(), "out": out.detach().numpy(),
+          "grad_x": x.grad.numpy()}
+    put_grads(st, rdb, full=("conv1.bias", "conv5.bias", "conv1.weight"))
+    weight_sums(st, rdb)
+    np.savez_compressed(os.path.join(HERE, "g1_rdb.npz"), **st)
+
+    # G2: one RRDB ----------------------------------------------------------------
+    torch.manual_seed(1)
+    rrdb = ref.RRDB(64, 32)
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(1, 64, 9, 7, generator=g).requires_grad_(True)
+    r = torch.randn(1, 64, 9, 7, generator=g)
+    out = rrdb(x)
+    (out * r).sum().backward()
+    st = {"seed": 1, "x": x.detach().numpy(), "r": r.numpy(), "out": out.detach().numpy(),
+          "grad_x": x.grad.numpy()}
+    put_grads(st, rrdb, full=("rdb3.conv5.bias", "rdb1.conv1.bias"))
+    weight_sums(st, rrdb)
+    np.savez_compressed(os.path.join(HERE, "g2_rrdb.npz"), **st)
+
+    # G3: 2-block generator, non-square input -------------------------------------
+    torch.manual_seed(2)
+    gen = ref.GeneratorRRDB(num_blocks=2)
+    with torch.no_grad():
+        gen.conv_last.bias += 0.5           # recipe: re-centre outputs into [0,1]
+    g = torch.Generator().manual_seed(102)
+    x = torch.rand(1, 3, 12, 10, generator=g).requires_grad_(True)
+    r = torch.randn(1, 3, 48, 40, generator=g)
+    out = gen(x)
+    (out * r).sum().backward()
+    st = {"seed": 2, "bias_shift": 0.5, "x": x.detach().numpy(), "r": r.numpy(),
+          "out": out.detach().numpy(), "grad_x": x.grad.numpy()}
+    put_grads(st, gen, full=("conv_first.weight", "conv_first.bias", "conv_last.weight",
+                             "conv_last.bias", "body.1.rdb3.conv5.bias", "trunk_conv.bias"))
+    weight_sums(st, gen)
+    np.savez_compressed(os.path.join(HERE, "g3_gen2.npz"), **st)
+
+    # G4: full 23-block generator -------------------------------------------------
+    torch.manual_seed(3)
+    gen = ref.GeneratorRRDB()
+    with torch.no_grad():
+        gen.conv_last.bias += 0.5
+    g = torch.Generator().manual_seed(103)
+    x = torch.rand(1, 3, 16, 16, generator=g)
+    out = gen(x)
+    torch.nn.functional.l1_loss(out, torch.zeros_like(out)).backward()
+    st = {"seed": 3, "bias_shift": 0.5, "x": x.numpy(), "out": out.detach().numpy(),
+          "n_keys": len(gen.state_dict()),
+          "n_params": sum(p.numel() for p in gen.parameters())}
+    put_grads(st, gen, full=("conv_first.weight", "conv_last.bias"))
+    st["gfull/body.22.rdb3.conv5.weight[:, :8]"] = \
+        gen.body[22].rdb3.conv5.weight.grad[:, :8].numpy().copy()
+    # keep the file small: drop the per-tensor samples of the 690 body tensors except block 0 and 22
+    for k in list(st):
+        if k.startswith("gs/body.") and not (k.startswith("gs/body.0.") or k.startswith("gs/body.22.")):
+            del st[k]
+    np.savez_compressed(os.path.join(HERE, "g4_gen23.npz"), **st)
+
+    # G5: state-dict manifest -----------------------------------------------------
+    with open(os.path.join(HERE, "g5_manifest.txt"), "w") as f:
+        for k, v in gen.state_dict().items():
+            f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+
+    # G6: discriminator, train and eval mode --------------------------------------
+    torch.manual_seed(4)
+    disc = ref.Discriminator()
+    g = torch.Generator().manual_seed(104)
+    img = torch.rand(2, 3, 128, 128, generator=g)
+    disc.train()
+    with torch.no_grad():
+        out_train = disc(img)
+    st = {"seed": 4, "img_seed": 104, "out_train": out_train.numpy(),
+          "running_mean_2": disc.model[3].running_mean.numpy().copy(),
+          "running_var_2": disc.model[3].running_var.numpy().copy()}
+    disc.eval()
+    with torch.no_grad():
+        st["out_eval"] = disc(img).numpy()
+    weight_sums(st, disc)
+    with open(os.path.join(HERE, "g6_disc_manifest.txt"), "w") as f:
+        for k, v in disc.state_dict().items():
+            f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+    np.savez_compressed(os.path.join(HERE, "g6_disc.npz"), **st)
+
+    # G7: pixel pre-training step (esrgan/train.py:156-161) ------------------------
+    torch.manual_seed(5)
+    gen = ref.GeneratorRRDB(num_blocks=2)
+    g = torch.Generator().manual_seed(105)
+    lr = torch.rand(2, 3, 8, 8, generator=g)
+    hr = torch.rand(2, 3, 32, 32, generator=g)
+    loss = torch.nn.L1Loss()(gen(lr), hr)
+    loss.backward()
+    st = {"seed": 5, "lr": lr.numpy(), "hr": hr.numpy(), "loss_pix": np.float64(loss.item())}
+    put_grads(st, gen, full=("conv_first.weight", "conv_last.weight", "body.0.rdb1.conv1.bias"))
+    np.savez_compressed(os.path.join(HERE, "g7_pixel_step.npz"), **st)
+
+    for fn in sorted(os.listdir(HERE)):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)))
+
+
+if __name__ == "__main__":
+    main()

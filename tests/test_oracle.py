@@ -1,0 +1,159 @@
+"""CPU: the oracle restatement against vectors produced by the reference classes themselves
+(tests/golden/make_golden.py).  Bit-exact where the same torch ops run in the same order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import esrgan_oracle as O
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def sub_state(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def check_grad_summary(g, grads, stride=97, rtol=1e-5):
+    names = [k[3:] for k in g if k.startswith("gs/")]
+    assert names
+    for name in names:
+        flat = grads[name].reshape(-1)
+        np.testing.assert_allclose(flat[::stride].numpy(), g[f"gs/{name}"], rtol=rtol, atol=1e-7)
+        assert abs(flat.double().abs().sum().item() - float(g[f"gabs/{name}"])) <= 1e-6 * max(1.0, float(g[f"gabs/{name}"]))
+    for k in g:
+        if k.startswith("gfull/") and "[" not in k:
+            np.testing.assert_allclose(grads[k[6:]].numpy(), g[k], rtol=rtol, atol=1e-7)
+
+
+def test_weight_recipe_matches_reference_constructor(golden):
+    # G3/G4/G7 store float64 sums of every weight the reference constructor drew from its seed.
+    for name, nb in (("g3_gen2.npz", 2), ("g4_gen23.npz", 23)):
+        g = golden(name)
+        sd = O.make_generator_state(int(g["seed"]), num_blocks=nb)
+        sd = O.center_outputs(sd, float(g["bias_shift"]))
+        for k, v in sd.items():
+            assert v.double().sum().item() == float(g[f"wsum/{k}"]) if f"wsum/{k}" in g else True
+    g = golden("g4_gen23.npz")
+    sd = O.make_generator_state(3)
+    assert len(sd) == int(g["n_keys"]) == 702
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"]) == 16697987
+
+
+def test_state_dict_manifest(golden):
+    import os
+    from conftest import GOLDEN
+    lines = open(os.path.join(GOLDEN, "g5_manifest.txt")).read().strip().splitlines()
+    sd = O.make_generator_state(0)
+    assert len(lines) == len(sd) == 702
+    for line, (k, v) in zip(lines, sd.items()):
+        name, rest = line.split(" ", 1)
+        assert name == k and rest.startswith(str(tuple(v.shape))) and rest.endswith("float32")
+
+
+def test_dense_block_g1(golden):
+    g = golden("g1_rdb.npz")
+    full = O.make_generator_state(0, num_blocks=0)  # not used: block weights are drawn alone below
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    sd = O.make_conv_state([(f"conv{k + 1}", 64 + 32 * k, 32 if k < 4 else 64) for k in range(5)], gen)
+    for k, v in sd.items():
+        assert v.double().sum().item() == float(g[f"wsum/{k}"])
+    x = t(g["x"]).requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.dense_block_forward(leaves, "", x)
+    assert torch.equal(out.detach(), t(g["out"]))
+    (out * t(g["r"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-5, atol=1e-7)
+    check_grad_summary(g, {k: v.grad for k, v in leaves.items()})
+
+
+def test_rrdb_g2(golden):
+    g = golden("g2_rrdb.npz")
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    specs = [(f"rdb{r}.conv{k + 1}", 64 + 32 * k, 32 if k < 4 else 64) for r in (1, 2, 3) for k in range(5)]
+    sd = O.make_conv_state(specs, gen)
+    x = t(g["x"]).requires_grad_(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.rrdb_forward(leaves, "", x)
+    assert torch.equal(out.detach(), t(g["out"]))
+    (out * t(g["r"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-5, atol=1e-7)
+    check_grad_summary(g, {k: v.grad for k, v in leaves.items()})
+
+
+def test_generator_g3_forward_backward(golden):
+    g = golden("g3_gen2.npz")
+    sd = O.center_outputs(O.make_generator_state(int(g["seed"]), num_blocks=2), float(g["bias_shift"]))
+    out, grads, gx = O.generator_grads(sd, t(g["x"]), t(g["r"]), input_grad=True)
+    assert torch.equal(out, t(g["out"]))
+    assert out.shape == (1, 3, 48, 40)
+    np.testing.assert_allclose(gx.numpy(), g["grad_x"], rtol=1e-5, atol=1e-7)
+    check_grad_summary(g, grads)
+
+
+def test_generator_g4_full(golden):
+    g = golden("g4_gen23.npz")
+    sd = O.center_outputs(O.make_generator_state(int(g["seed"])), float(g["bias_shift"]))
+    x = t(g["x"])
+    with torch.no_grad():
+        out = O.generator_forward(sd, x)
+    assert torch.equal(out, t(g["out"]))
+    frac = O.inside_unit_fraction(out)
+    assert frac > 0.9, frac      # the bias shift recipe keeps outputs inside (0,1)
+    # gradients under L1-to-zeros
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = O.generator_forward(leaves, x)
+    torch.nn.functional.l1_loss(o, torch.zeros_like(o)).backward()
+    grads = {k: v.grad for k, v in leaves.items()}
+    check_grad_summary(g, grads)
+    np.testing.assert_allclose(grads["body.22.rdb3.conv5.weight"][:, :8].numpy(),
+                               g["gfull/body.22.rdb3.conv5.weight[:, :8]"], rtol=1e-5, atol=1e-8)
+
+
+def test_discriminator_g6(golden):
+    g = golden("g6_disc.npz")
+    sd = O.make_discriminator_state(int(g["seed"]))
+    for k, v in sd.items():
+        # running stats in the fixture were saved after the train-mode forward: compare parameters only
+        if f"wsum/{k}" in g and "running" not in k:
+            assert v.double().sum().item() == float(g[f"wsum/{k}"]), k
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(int(g["img_seed"])))
+    train_sd = {k: v.clone() for k, v in sd.items()}
+    out_train = O.discriminator_forward(train_sd, img, training=True)
+    assert out_train.shape == (2, 1, 8, 8)
+    np.testing.assert_allclose(out_train.numpy(), g["out_train"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(train_sd["model.3.running_mean"].numpy(), g["running_mean_2"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(train_sd["model.3.running_var"].numpy(), g["running_var_2"], rtol=1e-5, atol=1e-7)
+    out_eval = O.discriminator_forward(train_sd, img, training=False)
+    np.testing.assert_allclose(out_eval.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_pixel_step_g7(golden):
+    g = golden("g7_pixel_step.npz")
+    sd = O.make_generator_state(int(g["seed"]), num_blocks=2)
+    loss, grads = O.pixel_step_grads(sd, t(g["lr"]), t(g["hr"]))
+    assert abs(loss - float(g["loss_pix"])) < 1e-7
+    check_grad_summary(g, grads)
+
+
+def test_tiled_forward_converges_to_full_image():
+    sd = O.make_generator_state(7, num_blocks=2)
+    x = torch.rand(1, 3, 40, 24, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        full = O.generator_forward(sd, x)
+        tiled = O.generator_forward_tiled(sd, x, bands=3, halo=35)   # halo >= receptive field: exact
+        narrow = O.generator_forward_tiled(sd, x, bands=3, halo=2)
+    assert tiled.shape == full.shape
+    assert (tiled - full).abs().max().item() < 1e-5
+    assert (narrow - full).abs().max().item() > (tiled - full).abs().max().item()
+
+
+def test_bf16_emulation_is_close_but_not_equal():
+    sd = O.center_outputs(O.make_generator_state(11, num_blocks=3))
+    x = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        ref = O.generator_forward(sd, x)
+        emu = O.generator_forward(sd, x, emulate_bf16=True)
+    assert not torch.equal(ref, emu)
+    assert O.psnr(ref.clamp(0, 1), emu.clamp(0, 1)) > 45.0
