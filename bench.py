@@ -75,23 +75,25 @@ def measure_kernels(net, N, H, W, reps=10):
     t5b = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None))
     rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b))
     # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
-    w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt)
-    wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt)
+    sp = 1 if net.hr_split else 0   # HR-side convs carry the weight rounding residue (2x MFMA work)
+    wt, bt = ops.pack_weight(net.trunk_conv.weight.detach(), net.trunk_conv.bias.detach(), dt)
+    w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt, sp)
+    wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt, sp)
     lr = torch.zeros((N, H, nf // 8, W, 8), dtype=torch.bfloat16, device=dev).normal_()
     h1 = torch.empty((N, 2 * H, nf // 8, 2 * W, 8), dtype=torch.bfloat16, device=dev)
     h2 = torch.empty((N, 4 * H, nf // 8, 4 * W, 8), dtype=torch.bfloat16, device=dev)
     h3 = torch.empty_like(h2)
     out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
     nu = nf // 8
-    ta = timed(lambda: ops.conv3x3_fwd(lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None))
+    ta = timed(lambda: ops.conv3x3_fwd(lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, sp))
     rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta))
-    tb = timed(lambda: ops.conv3x3_fwd(h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None))
+    tb = timed(lambda: ops.conv3x3_fwd(h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, sp))
     rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb))
-    tc = timed(lambda: ops.conv3x3_fwd(h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None))
+    tc = timed(lambda: ops.conv3x3_fwd(h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, sp))
     rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc))
-    td = timed(lambda: ops.conv3x3_fwd(h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out))
+    td = timed(lambda: ops.conv3x3_fwd(h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, sp))
     rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td))
-    tt = timed(lambda: ops.conv3x3_fwd(buf, nu, w64, b64, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None))
+    tt = timed(lambda: ops.conv3x3_fwd(buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None))
     rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt))
     return rows
 

@@ -38,7 +38,18 @@ extern "C" {
 #define SR355_DTYPE_BF16 0       /* bf16 storage, fp32 accumulate (32x32x16 MFMA) */
 #define SR355_DTYPE_F32 1        /* fp32 storage, exact fp32 MFMA (32x32x2)        */
 
-#define SR355_ABI_VERSION 1
+/* Split modes (bf16 only).  A bf16 product keeps 8 significant bits per factor; where that is
+ * not enough the rounding residue is carried as extra terms of the same MFMA accumulation:
+ *   SPLIT_WEIGHT: packed weights hold hi = bf16(w) and lo = bf16(w - hi); the conv runs over the
+ *                 input twice (hi pass, lo pass) -> weight rounding error ~2^-17 instead of 2^-9.
+ *   SPLIT_INPUT : as SPLIT_WEIGHT, and the input buffer holds bf16(x) in channels [0,C) and the
+ *                 residue bf16(x - bf16(x)) in channels [C,2C) (sr355_nchw_to_blocked split=1);
+ *                 used for the first conv, whose 3 input channels leave the K dimension idle. */
+#define SR355_SPLIT_NONE 0
+#define SR355_SPLIT_WEIGHT 1
+#define SR355_SPLIT_INPUT 2
+
+#define SR355_ABI_VERSION 2
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -48,9 +59,10 @@ int sr355_unit_channels(int dtype);
 
 /* ---- layout conversion (module boundary: NCHW fp32 tensors, esrgan_model.py:55,:62) ---- */
 
-/* src [N][C][H][W] fp32 -> dst blocked [N][H][dst_units][W][unit]; channels >= C are zero. */
+/* src [N][C][H][W] fp32 -> dst blocked [N][H][dst_units][W][unit]; channels >= C are zero.
+ * split=1 (bf16): channels [C,2C) receive the bf16 rounding residue of channels [0,C). */
 int sr355_nchw_to_blocked(const float *src_dev, int N, int C, int H, int W, int dtype,
-                          void *dst_dev, int dst_units, size_t dst_bytes, void *stream);
+                          void *dst_dev, int dst_units, int split, size_t dst_bytes, void *stream);
 /* blocked units [unit_off, unit_off + ceil(C/unit)) -> dst [N][C][H][W] fp32. */
 int sr355_blocked_to_nchw(const void *src_dev, int src_units, int unit_off, int dtype,
                           int N, int C, int H, int W, float *dst_dev, size_t dst_bytes,
@@ -58,12 +70,13 @@ int sr355_blocked_to_nchw(const void *src_dev, int src_units, int unit_off, int 
 
 /* ---- weights: OIHW fp32 (the state_dict layout, kept as the parameter) -> packed ---- */
 
-/* Packed layout [cin_units][9][cout_pad][unit]; cout_pad = round_up(cout, 32),
- * cin_units = round_up(ceil(cin/unit), 2).  Returns bytes (0 on bad args). */
-size_t sr355_packed_weight_bytes(int cout, int cin, int dtype);
+/* Packed layout [units][9][cout_pad][unit]; cout_pad = round_up(cout, 32),
+ * units = round_up(ceil(cin/unit), 2), doubled by a split mode (residue image appended;
+ * SPLIT_INPUT counts 2*cin channels).  Returns bytes (0 on bad args). */
+size_t sr355_packed_weight_bytes(int cout, int cin, int dtype, int split);
 /* bias_packed_dev receives cout_pad floats (zero padded).  */
 int sr355_pack_weight(const float *w_oihw_dev, const float *bias_dev, int cout, int cin,
-                      int dtype, void *w_packed_dev, size_t w_packed_bytes,
+                      int dtype, int split, void *w_packed_dev, size_t w_packed_bytes,
                       float *bias_packed_dev, void *stream);
 
 /* ---- the convolution op (replaces nn.Conv2d 3x3/s1/p1 + its fused neighbours) ---- */
@@ -77,6 +90,7 @@ typedef struct sr355_conv_args {
     int cin_units;             /* units consumed: channels [0, cin_units*unit); even       */
     const void *w_packed_dev;  /* sr355_pack_weight output                                 */
     size_t w_packed_bytes;
+    int weight_split;          /* SR355_SPLIT_*: the mode the weights were packed with     */
     const float *bias_packed_dev;
     int cout;                  /* real output channels                                     */
     float lrelu_slope;         /* 1.0f = no activation                                     */
@@ -101,6 +115,8 @@ typedef struct sr355_generator_cfg {
     int in_channels, out_channels, num_features, num_blocks, growth_channels; /* :42 */
     int dtype;
     int trunk_fp32;            /* 1: residual trunk carried in fp32 beside the bf16 copy  */
+    int hr_split;              /* 1 (bf16): SPLIT_INPUT on conv_first and SPLIT_WEIGHT on the
+                                  four HR-side convs (upconv1/2, HR_conv, conv_last)       */
 } sr355_generator_cfg;
 
 /* Number of 3x3 convs (351 for the default config). */

@@ -19,10 +19,11 @@ themselves (``tests/golden/make_golden.py``, run in the build container where
 here against those vectors bit-for-bit.  The reference has no tests or golden
 vectors of its own for this path.
 
-``emulate_bf16=True`` is NOT part of the reference: it models the storage
-rounding points of the bf16 HIP path (weights and every conv input rounded to
-bf16, fp32 accumulation, fp32 residual trunk) so the bf16 kernels can be checked
-at a tight tolerance in addition to the PSNR gate against the fp32 result.
+``emulate_bf16`` is NOT part of the reference: it models the storage rounding
+points of the bf16 HIP path (weights and every conv input rounded to bf16, fp32
+accumulation, fp32 residual trunk; "hr_split" additionally models the convs
+whose rounding residue the HIP path carries) so the bf16 kernels can be checked
+against a like-for-like CPU computation besides the PSNR gate against fp32.
 """
 from __future__ import annotations
 
@@ -111,14 +112,24 @@ def _bf16r(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def _conv(sd: StateDict, name: str, x: torch.Tensor, emulate_bf16: bool, stride: int = 1) -> torch.Tensor:
+_HR_SIDE = ("upconv1", "upconv2", "HR_conv", "conv_last")
+
+
+def _conv(sd: StateDict, name: str, x: torch.Tensor, emulate_bf16, stride: int = 1) -> torch.Tensor:
+    """``emulate_bf16``: False = fp32 (the reference); True = every conv rounds weights and input to
+    bf16; "hr_split" = as True, except that the HR-side convs keep their weights exact and
+    conv_first keeps weights and input exact (the residue-carrying modes of the HIP path)."""
     w, b = sd[name + ".weight"], sd[name + ".bias"]
     if emulate_bf16:
-        w, x = _bf16r(w), _bf16r(x)
+        split = emulate_bf16 == "hr_split"
+        if not (split and (name in _HR_SIDE or name == "conv_first")):
+            w = _bf16r(w)
+        if not (split and name == "conv_first"):
+            x = _bf16r(x)
     return F.conv2d(x, w, b, stride=stride, padding=1)
 
 
-def dense_block_forward(sd: StateDict, prefix: str, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+def dense_block_forward(sd: StateDict, prefix: str, x: torch.Tensor, emulate_bf16=False) -> torch.Tensor:
     """esrgan_model.py:18-24 — four growth convs on the running concatenation, then conv5."""
     feats = [x]
     for k in range(1, 5):
@@ -128,7 +139,7 @@ def dense_block_forward(sd: StateDict, prefix: str, x: torch.Tensor, emulate_bf1
     return x + x5 * RES_SCALE
 
 
-def rrdb_forward(sd: StateDict, prefix: str, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+def rrdb_forward(sd: StateDict, prefix: str, x: torch.Tensor, emulate_bf16=False) -> torch.Tensor:
     """esrgan_model.py:35-39."""
     out = x
     for r in (1, 2, 3):
@@ -143,7 +154,7 @@ def count_blocks(sd: StateDict) -> int:
     return n
 
 
-def generator_forward(sd: StateDict, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+def generator_forward(sd: StateDict, x: torch.Tensor, emulate_bf16=False) -> torch.Tensor:
     """esrgan_model.py:55-62.  ``x`` is [B,3,H,W] fp32; returns [B,3,4H,4W] fp32, unclamped."""
     fea = _conv(sd, "conv_first", x, emulate_bf16)
     body = fea

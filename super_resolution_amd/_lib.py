@@ -15,7 +15,8 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 
 # every symbol include/sr355.h declares
 EXPORTS = (
@@ -34,7 +35,7 @@ class ConvArgs(C.Structure):
         ("dtype", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("upsample", C.c_int),
         ("in_dev", C.c_void_p), ("in_bytes", C.c_size_t),
         ("in_units", C.c_int), ("cin_units", C.c_int),
-        ("w_packed_dev", C.c_void_p), ("w_packed_bytes", C.c_size_t),
+        ("w_packed_dev", C.c_void_p), ("w_packed_bytes", C.c_size_t), ("weight_split", C.c_int),
         ("bias_packed_dev", C.c_void_p),
         ("cout", C.c_int), ("lrelu_slope", C.c_float),
         ("res1_dev", C.c_void_p), ("res1_scale", C.c_float),
@@ -52,7 +53,7 @@ class GeneratorCfg(C.Structure):
     _fields_ = [
         ("in_channels", C.c_int), ("out_channels", C.c_int), ("num_features", C.c_int),
         ("num_blocks", C.c_int), ("growth_channels", C.c_int), ("dtype", C.c_int),
-        ("trunk_fp32", C.c_int),
+        ("trunk_fp32", C.c_int), ("hr_split", C.c_int),
     ]
 
 
@@ -87,11 +88,11 @@ def lib() -> C.CDLL:
     L.sr355_abi_version.restype = i
     L.sr355_last_error.restype = C.c_char_p
     L.sr355_unit_channels.argtypes = [i]
-    L.sr355_nchw_to_blocked.argtypes = [vp, i, i, i, i, i, vp, i, sz, vp]
+    L.sr355_nchw_to_blocked.argtypes = [vp, i, i, i, i, i, vp, i, i, sz, vp]
     L.sr355_blocked_to_nchw.argtypes = [vp, i, i, i, i, i, i, i, vp, sz, vp]
-    L.sr355_packed_weight_bytes.argtypes = [i, i, i]
+    L.sr355_packed_weight_bytes.argtypes = [i, i, i, i]
     L.sr355_packed_weight_bytes.restype = sz
-    L.sr355_pack_weight.argtypes = [vp, vp, i, i, i, vp, sz, vp, vp]
+    L.sr355_pack_weight.argtypes = [vp, vp, i, i, i, i, vp, sz, vp, vp]
     L.sr355_conv3x3_fwd.argtypes = [C.POINTER(ConvArgs), vp]
     L.sr355_generator_num_convs.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.argtypes = [C.POINTER(GeneratorCfg)]

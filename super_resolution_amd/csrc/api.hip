@@ -33,7 +33,7 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 // ---- generator geometry -------------------------------------------------------------------
 struct ConvSpec {
-    int cin, cout;
+    int cin, cout, split;
     size_t w_off, b_off;  // offsets into the packed blob
 };
 
@@ -60,16 +60,19 @@ static bool cfg_ok(const sr355_generator_cfg *c) {
 static std::vector<ConvSpec> conv_specs(const sr355_generator_cfg &c, size_t *total_bytes) {
     std::vector<ConvSpec> v;
     const int nf = c.num_features, gc = c.growth_channels;
-    v.push_back({c.in_channels, nf, 0, 0});
+    const bool split = c.hr_split && c.dtype == SR355_DTYPE_BF16;
+    const int hs = split ? SR355_SPLIT_WEIGHT : SR355_SPLIT_NONE;
+    v.push_back({c.in_channels, nf, split ? SR355_SPLIT_INPUT : SR355_SPLIT_NONE, 0, 0});
     for (int b = 0; b < c.num_blocks; ++b)
         for (int r = 0; r < 3; ++r)
-            for (int k = 0; k < 5; ++k) v.push_back({nf + gc * k, k < 4 ? gc : nf, 0, 0});
-    for (int i = 0; i < 4; ++i) v.push_back({nf, nf, 0, 0});
-    v.push_back({nf, c.out_channels, 0, 0});
+            for (int k = 0; k < 5; ++k) v.push_back({nf + gc * k, k < 4 ? gc : nf, SR355_SPLIT_NONE, 0, 0});
+    v.push_back({nf, nf, SR355_SPLIT_NONE, 0, 0});              // trunk_conv
+    for (int i = 0; i < 3; ++i) v.push_back({nf, nf, hs, 0, 0});  // upconv1, upconv2, HR_conv
+    v.push_back({nf, c.out_channels, hs, 0, 0});                 // conv_last
     size_t off = 0;
     for (auto &s : v) {
         s.w_off = off;
-        off += align256(sr355_packed_weight_bytes(s.cout, s.cin, c.dtype));
+        off += align256(sr355_packed_weight_bytes(s.cout, s.cin, c.dtype, s.split));
         s.b_off = off;
         off += align256((size_t)cout_pad_for(s.cout) * sizeof(float));
     }
@@ -86,7 +89,8 @@ static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
     Workspace w;
     const int cpu = unit_channels(c.dtype);
     const size_t P = (size_t)N * H * W;
-    w.in_units = cin_units_for(c.in_channels, c.dtype);
+    w.in_units = real_units_for(c.in_channels, c.dtype,
+                                (c.hr_split && c.dtype == SR355_DTYPE_BF16) ? SR355_SPLIT_INPUT : SR355_SPLIT_NONE);
     w.nf_units = c.num_features / cpu;
     w.blk_units = (c.num_features + 4 * c.growth_channels) / cpu;
     w.f32_units = c.num_features / 4;
@@ -121,9 +125,10 @@ const char *sr355_last_error(void) { return g_err; }
 int sr355_unit_channels(int dtype) { return unit_channels(dtype); }
 
 int sr355_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst, int dst_units,
-                          size_t dst_bytes, void *stream) {
+                          int split, size_t dst_bytes, void *stream) {
     const int cpu = unit_channels(dtype);
-    if (cpu < 0 || !src || !dst || N < 1 || C < 1 || H < 1 || W < 1 || dst_units * cpu < C) {
+    if (cpu < 0 || !src || !dst || N < 1 || C < 1 || H < 1 || W < 1 || dst_units * cpu < (split ? 2 * C : C) ||
+        (split && dtype != SR355_DTYPE_BF16)) {
         set_error("nchw_to_blocked: bad arguments (dtype=%d N=%d C=%d H=%d W=%d units=%d)", dtype, N, C, H, W,
                   dst_units);
         return SR355_ERR_INVALID;
@@ -132,7 +137,7 @@ int sr355_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtyp
         set_error("nchw_to_blocked: destination too small or not 16-byte aligned");
         return SR355_ERR_INVALID;
     }
-    return launch_nchw_to_blocked(src, N, C, H, W, dtype, dst, dst_units, (hipStream_t)stream);
+    return launch_nchw_to_blocked(src, N, C, H, W, dtype, dst, dst_units, split ? 1 : 0, (hipStream_t)stream);
 }
 
 int sr355_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C, int H, int W,
@@ -151,20 +156,25 @@ int sr355_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtyp
     return launch_blocked_to_nchw(src, src_units, unit_off, dtype, N, C, H, W, dst, (hipStream_t)stream);
 }
 
-size_t sr355_packed_weight_bytes(int cout, int cin, int dtype) {
-    if (unit_channels(dtype) < 0 || cout < 1 || cin < 1) return 0;
-    return (size_t)cin_units_for(cin, dtype) * 9 * cout_pad_for(cout) * 16;
+static bool split_ok(int dtype, int split) {
+    return split == SR355_SPLIT_NONE ||
+           (dtype == SR355_DTYPE_BF16 && (split == SR355_SPLIT_WEIGHT || split == SR355_SPLIT_INPUT));
 }
 
-int sr355_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp, size_t wp_bytes,
-                      float *bp, void *stream) {
-    const size_t need = sr355_packed_weight_bytes(cout, cin, dtype);
+size_t sr355_packed_weight_bytes(int cout, int cin, int dtype, int split) {
+    if (unit_channels(dtype) < 0 || cout < 1 || cin < 1 || !split_ok(dtype, split)) return 0;
+    return (size_t)packed_units_for(cin, dtype, split) * 9 * cout_pad_for(cout) * 16;
+}
+
+int sr355_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split, void *wp,
+                      size_t wp_bytes, float *bp, void *stream) {
+    const size_t need = sr355_packed_weight_bytes(cout, cin, dtype, split);
     if (!need || !w || !wp || !aligned16(wp) || wp_bytes < need) {
         set_error("pack_weight: bad arguments (cout=%d cin=%d dtype=%d bytes=%zu need=%zu)", cout, cin, dtype,
                   wp_bytes, need);
         return SR355_ERR_INVALID;
     }
-    return launch_pack_weight(w, bias, cout, cin, dtype, wp, bp, (hipStream_t)stream);
+    return launch_pack_weight(w, bias, cout, cin, dtype, split, wp, bp, (hipStream_t)stream);
 }
 
 int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
@@ -204,8 +214,9 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     }
     const int cout_pad = cout_pad_for(p->cout);
     if (!p->w_packed_dev || !aligned16(p->w_packed_dev) || !p->bias_packed_dev || !aligned16(p->bias_packed_dev) ||
-        p->w_packed_bytes < (size_t)p->cin_units * 9 * cout_pad * 16) {
-        set_error("conv3x3_fwd: packed weights/bias missing, misaligned or too small");
+        !split_ok(p->dtype, p->weight_split) ||
+        p->w_packed_bytes < (size_t)p->cin_units * (p->weight_split ? 2 : 1) * 9 * cout_pad * 16) {
+        set_error("conv3x3_fwd: packed weights/bias missing, misaligned, too small or bad split mode");
         return SR355_ERR_INVALID;
     }
     if (!p->out_act_dev && !p->out_f32_dev && !p->out_nchw_dev) {
@@ -263,7 +274,7 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     a.cout_real = p->cout;
     a.cout_pad = cout_pad;
     a.f32_units = p->cout / 4;
-    return launch_conv3x3(a, p->dtype, p->cin_units, (hipStream_t)stream);
+    return launch_conv3x3(a, p->dtype, p->cin_units, p->weight_split != SR355_SPLIT_NONE, (hipStream_t)stream);
 }
 
 // ---- generator ----------------------------------------------------------------------------
@@ -296,7 +307,7 @@ int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_p
             set_error("generator_pack: tensor %zu is null", i);
             return SR355_ERR_INVALID;
         }
-        int rc = launch_pack_weight(w_ptrs[i], b_ptrs[i], specs[i].cout, specs[i].cin, cfg->dtype,
+        int rc = launch_pack_weight(w_ptrs[i], b_ptrs[i], specs[i].cout, specs[i].cin, cfg->dtype, specs[i].split,
                                     base + specs[i].w_off, (float *)(base + specs[i].b_off), (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -337,7 +348,8 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
     const unsigned char *pk = (const unsigned char *)packed;
     float *T = (float *)(wsb + ws.T), *R = (float *)(wsb + ws.R), *F = (float *)(wsb + ws.F);
 
-    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, wsb + ws.x0, ws.in_units, stream);
+    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, wsb + ws.x0, ws.in_units,
+                                    specs[0].split == SR355_SPLIT_INPUT, stream);
     if (rc) return rc;
 
     size_t ci = 0;  // running conv index
@@ -368,7 +380,7 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
         a.cout_real = sp.cout;
         a.cout_pad = cout_pad_for(sp.cout);
         a.f32_units = sp.cout / 4;
-        return launch_conv3x3(a, dtype, cin_units, stream);
+        return launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, stream);
     };
 
     unsigned char *cur = wsb + ws.bufA, *nxt = wsb + ws.bufB;

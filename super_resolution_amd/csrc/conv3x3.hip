@@ -17,6 +17,12 @@
 // haloed input tile and [unit][tap][cout][16 B] for the weights, so every fragment read is a
 // conflict-free ds_read_b128 of 32 consecutive 16-byte slots per half-wave.
 // For one kx the (NB+2) input rows are read once and reused by the three ky taps.
+//
+// Split weights (bf16 only): the packed weights may carry a second image holding the bf16
+// rounding residue of every weight (w = hi + lo).  The kernel then runs n_stages = 2 * n_real
+// stages; stage s >= n_real re-reads input stage s - n_real against the residue weights, which
+// removes the weight-rounding error at twice the MFMA count.  Used for the four HR-side convs
+// and conv_first, whose weight rounding dominates the bf16 output error.
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -118,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
     u32x4 sin[G::KIN], sw[G::KW];
 #define SR355_STAGE_LOAD(S)                                                                      \
     {                                                                                            \
-        const unsigned char *ip_ = in_img + (size_t)(S) * in_stage_stride;                       \
+        const int si_ = (S) >= n_real ? (S) - n_real : (S); /* split weights: input stages wrap */ \
+        const unsigned char *ip_ = in_img + (size_t)si_ * in_stage_stride;                       \
         const unsigned char *wp_ = w_base + (size_t)(S) * w_stage_stride;                        \
         _Pragma("unroll") for (int k = 0; k < G::KIN; ++k) {                                     \
             const u32x4 *src_ = reinterpret_cast<const u32x4 *>(ip_ + (goff[k] >= 0 ? goff[k] : 0)); \
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
 
+    const int n_real = a.n_real_stages;
     const int lane_in = (h * G::NPIX + wave * NB * TWP + r) * 16;
     const int lane_w = G::IN_BYTES + (h * 9 * G::CO + r) * 16;
 
@@ -295,13 +303,18 @@ static int launch_nb(const ConvArgs &a, hipStream_t stream) {
     return launch_inst<T, MB, 1, SU>(a, stream);
 }
 
-int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, hipStream_t stream) {
+int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split, hipStream_t stream) {
     if (cin_units <= 0 || (cin_units & 1)) {
         set_error("conv3x3: cin_units=%d must be a positive even number", cin_units);
         return SR355_ERR_INVALID;
     }
     ConvArgs b = a;
-    b.n_stages = cin_units / 2;
+    if (weight_split && dtype != SR355_DTYPE_BF16) {
+        set_error("conv3x3: split weights exist only for the bf16 path");
+        return SR355_ERR_INVALID;
+    }
+    b.n_real_stages = cin_units / 2;
+    b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
     const bool wide = (a.cout_pad % 64) == 0;
     if (dtype == SR355_DTYPE_BF16)
         return wide ? launch_nb<__bf16, 2, 2>(b, stream) : launch_nb<__bf16, 1, 2>(b, stream);

@@ -13,9 +13,11 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
 // One thread per (n, y, unit, x): gathers CPU channels from NCHW and writes one 16-byte unit.
+// split != 0 (bf16): channels [0,C) hold bf16(x) and channels [C,2C) the rounding residue
+// bf16(x - bf16(x)), so a conv over both sees x to ~16 bits.
 template <typename T>
 __global__ void nchw_to_blocked_kernel(const float *__restrict__ src, T *__restrict__ dst, int N, int C,
-                                       int H, int W, int U) {
+                                       int H, int W, int U, int split) {
     constexpr int CPU = 16 / sizeof(T);
     const size_t total = (size_t)N * H * U * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
@@ -30,7 +32,14 @@ __global__ void nchw_to_blocked_kernel(const float *__restrict__ src, T *__restr
 #pragma unroll
         for (int e = 0; e < CPU; ++e) {
             const int c = u * CPU + e;
-            v[e] = from_f32<T>(c < C ? src[(((size_t)n * C + c) * H + y) * W + x] : 0.f);
+            float f = 0.f;
+            if (c < C) {
+                f = src[(((size_t)n * C + c) * H + y) * W + x];
+            } else if (split && c < 2 * C) {
+                const float full = src[(((size_t)n * C + c - C) * H + y) * W + x];
+                f = full - (float)from_f32<T>(full);
+            }
+            v[e] = from_f32<T>(f);
         }
         uint4 pk;
         __builtin_memcpy(&pk, v, 16);
@@ -58,22 +67,33 @@ __global__ void blocked_to_nchw_kernel(const T *__restrict__ src, float *__restr
 }
 
 // One thread per packed unit (u, tap, co): CPU input channels of one output channel and tap.
+// Image 0 (units [0,U)) holds the rounded weights; with a split mode image 1 (units [U,2U)) holds
+// the rounding residue w - round(w).  SR355_SPLIT_INPUT additionally repeats the rounded weights on
+// channels [cin, 2cin) of image 0, where the input carries its own residue.
 template <typename T>
 __global__ void pack_weight_kernel(const float *__restrict__ w, const float *__restrict__ bias,
                                    T *__restrict__ wp, float *__restrict__ bp, int cout, int cin,
-                                   int cin_units, int cout_pad) {
+                                   int U, int cout_pad, int split) {
     constexpr int CPU = 16 / sizeof(T);
-    const int total = cin_units * 9 * cout_pad;
+    const int total = U * (split ? 2 : 1) * 9 * cout_pad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int co = i % cout_pad;
         const int t = i / cout_pad;
         const int tap = t % 9;
-        const int u = t / 9;
+        const int uu = t / 9;
+        const int image = uu >= U ? 1 : 0;
+        const int u = uu - image * U;
         T v[CPU];
 #pragma unroll
         for (int e = 0; e < CPU; ++e) {
-            const int ci = u * CPU + e;
-            v[e] = from_f32<T>((co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] : 0.f);
+            int ci = u * CPU + e;
+            if (split == SR355_SPLIT_INPUT && image == 0 && ci >= cin) ci -= cin;
+            float f = 0.f;
+            if (co < cout && ci < cin && (u * CPU + e) < (split == SR355_SPLIT_INPUT && image == 0 ? 2 * cin : cin)) {
+                f = w[((size_t)co * cin + ci) * 9 + tap];
+                if (image) f = f - (float)from_f32<T>(f);
+            }
+            v[e] = from_f32<T>(f);
         }
         uint4 pk;
         __builtin_memcpy(&pk, v, 16);
@@ -88,14 +108,14 @@ static unsigned grid_for(size_t total) {
 }
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
-                           int dst_units, hipStream_t stream) {
+                           int dst_units, int split, hipStream_t stream) {
     const size_t total = (size_t)N * H * dst_units * W;
     if (dtype == SR355_DTYPE_BF16)
         hipLaunchKernelGGL(nchw_to_blocked_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, src,
-                           (__bf16 *)dst, N, C, H, W, dst_units);
+                           (__bf16 *)dst, N, C, H, W, dst_units, split);
     else
         hipLaunchKernelGGL(nchw_to_blocked_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src,
-                           (float *)dst, N, C, H, W, dst_units);
+                           (float *)dst, N, C, H, W, dst_units, 0);
     return check_hip(hipGetLastError(), "nchw_to_blocked launch");
 }
 
@@ -111,16 +131,16 @@ int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dty
     return check_hip(hipGetLastError(), "blocked_to_nchw launch");
 }
 
-int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp,
-                       float *bp, hipStream_t stream) {
-    const int cu = cin_units_for(cin, dtype), cp = cout_pad_for(cout);
-    const size_t total = (size_t)cu * 9 * cp;
+int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,
+                       void *wp, float *bp, hipStream_t stream) {
+    const int cu = real_units_for(cin, dtype, split), cp = cout_pad_for(cout);
+    const size_t total = (size_t)packed_units_for(cin, dtype, split) * 9 * cp;
     if (dtype == SR355_DTYPE_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, w, bias,
-                           (__bf16 *)wp, bp, cout, cin, cu, cp);
+                           (__bf16 *)wp, bp, cout, cin, cu, cp, split);
     else
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, bias,
-                           (float *)wp, bp, cout, cin, cu, cp);
+                           (float *)wp, bp, cout, cin, cu, cp, 0);
     return check_hip(hipGetLastError(), "pack_weight launch");
 }
 

@@ -23,7 +23,8 @@ struct ConvArgs {
     float slope;                 // LeakyReLU slope, 1.0f = identity
     int N, H, W;                 // output dims
     int in_units;                // units per pixel of the input buffer
-    int n_stages;                // cin_units / SU
+    int n_stages;                // stages to run (2 * n_real_stages with split weights)
+    int n_real_stages;           // cin_units / SU: stages of real input
     int ups;                     // 0 | 1
     int out_units, out_unit_off; // geometry of out_act
     int cout_real, cout_pad;
@@ -35,18 +36,26 @@ void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 
 // Launch the MFMA conv.  cin_units must be even; returns SR355_* code.
-int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, hipStream_t stream);
+int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split, hipStream_t stream);
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
-                           int dst_units, hipStream_t stream);
+                           int dst_units, int split, hipStream_t stream);
 int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C,
                            int H, int W, float *dst, hipStream_t stream);
-int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, void *wp,
-                       float *bp, hipStream_t stream);
+int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,
+                       void *wp, float *bp, hipStream_t stream);
 
 inline int unit_channels(int dtype) { return dtype == SR355_DTYPE_BF16 ? 8 : dtype == SR355_DTYPE_F32 ? 4 : -1; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int cin_units_for(int cin, int dtype) { return round_up((cin + unit_channels(dtype) - 1) / unit_channels(dtype), 2); }
 inline int cout_pad_for(int cout) { return round_up(cout, 32); }
+// Units of real input a conv consumes under a split mode (input split doubles the channels).
+inline int real_units_for(int cin, int dtype, int split) {
+    return cin_units_for(split == SR355_SPLIT_INPUT ? 2 * cin : cin, dtype);
+}
+// Units of the packed weight image (both split modes append the residue image).
+inline int packed_units_for(int cin, int dtype, int split) {
+    return real_units_for(cin, dtype, split) * (split ? 2 : 1);
+}
 
 }  // namespace sr355

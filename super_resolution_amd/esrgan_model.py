@@ -131,11 +131,16 @@ class RRDB(nn.Module):
 
 class GeneratorRRDB(nn.Module):
     """ESRGAN x4 generator.  ``precision`` selects the kernel arithmetic: ``"bf16"`` (bf16 storage,
-    fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path)."""
+    fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path).
+    ``hr_split`` (bf16 only) carries the bf16 rounding residue of the weights of the four
+    HR-side convs, and of the input and weights of conv_first, as extra MFMA terms; their rounding
+    otherwise dominates the output error (50.0 dB -> 53.9 dB PSNR against fp32 at +8 % MFMA work)."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, num_features: int = 64,
-                 num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16"):
+                 num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16",
+                 hr_split: bool = True):
         super().__init__()
+        self.hr_split = bool(hr_split)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -161,14 +166,15 @@ class GeneratorRRDB(nn.Module):
         return mods
 
     def cfg(self) -> List[int]:
+        dtype = _PRECISIONS[self.precision]
         return [self.in_channels, self.out_channels, self.num_features, self.num_blocks,
-                self.growth_channels, _PRECISIONS[self.precision]]
+                self.growth_channels, dtype, int(self.hr_split and dtype == DTYPE_BF16)]
 
     def packed_parameters(self) -> Tensor:
         convs = self.conv_modules()
         params = [p for c in convs for p in (c.weight, c.bias)]
         cfg = self.cfg()
-        return self._cache.get(params, cfg[5], lambda: ops.generator_pack(
+        return self._cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack(
             [c.weight.detach() for c in convs], [c.bias.detach() for c in convs], cfg))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:

@@ -44,21 +44,22 @@ def _nbytes(t: Optional[Tensor]) -> int:
 
 # ------------------------------------------------------------------------------------
 @torch.library.custom_op("sr355::to_blocked", mutates_args=())
-def to_blocked(x: Tensor, units: int, dtype: int) -> Tensor:
-    """NCHW fp32 -> blocked [N,H,units,W,c]; channels beyond C are zero."""
+def to_blocked(x: Tensor, units: int, dtype: int, split: int = 0) -> Tensor:
+    """NCHW fp32 -> blocked [N,H,units,W,c]; channels beyond C are zero (split=1: channels [C,2C)
+    carry the bf16 rounding residue of channels [0,C))."""
     _need_cuda(x)
     if x.dtype != torch.float32 or x.dim() != 4:
         raise RuntimeError("to_blocked expects an fp32 NCHW tensor")
     N, Cc, H, W = x.shape
     out = torch.empty((N, H, units, W, UNIT_CHANNELS[dtype]), dtype=_TORCH_DTYPE[dtype], device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib().sr355_nchw_to_blocked(x.data_ptr(), N, Cc, H, W, dtype, out.data_ptr(), units,
+        check(_lib.lib().sr355_nchw_to_blocked(x.data_ptr(), N, Cc, H, W, dtype, out.data_ptr(), units, split,
                                                _nbytes(out), _stream()), "sr355_nchw_to_blocked")
     return out
 
 
 @to_blocked.register_fake
-def _(x, units, dtype):
+def _(x, units, dtype, split=0):
     N, _c, H, W = x.shape
     return x.new_empty((N, H, units, W, UNIT_CHANNELS[dtype]), dtype=_TORCH_DTYPE[dtype])
 
@@ -82,27 +83,30 @@ def _(buf, unit_off, channels):
 
 
 @torch.library.custom_op("sr355::pack_weight", mutates_args=())
-def pack_weight(w: Tensor, bias: Tensor, dtype: int) -> Tuple[Tensor, Tensor]:
-    """OIHW fp32 weight + bias -> (packed weight bytes, zero-padded fp32 bias)."""
+def pack_weight(w: Tensor, bias: Tensor, dtype: int, split: int = 0) -> Tuple[Tensor, Tensor]:
+    """OIHW fp32 weight + bias -> (packed weight bytes, zero-padded fp32 bias).  ``split`` is one of
+    the SR355_SPLIT_* modes of include/sr355.h (bf16 only)."""
     _need_cuda(w, bias)
     if w.dtype != torch.float32 or w.dim() != 4 or w.shape[2:] != (3, 3):
         raise RuntimeError("pack_weight expects an fp32 [cout, cin, 3, 3] tensor")
     cout, cin = int(w.shape[0]), int(w.shape[1])
     L = _lib.lib()
-    nbytes = L.sr355_packed_weight_bytes(cout, cin, dtype)
+    nbytes = L.sr355_packed_weight_bytes(cout, cin, dtype, split)
+    if nbytes == 0:
+        check(-1, "sr355_packed_weight_bytes")
     wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        check(L.sr355_pack_weight(w.data_ptr(), bias.data_ptr(), cout, cin, dtype, wp.data_ptr(), nbytes,
+        check(L.sr355_pack_weight(w.data_ptr(), bias.data_ptr(), cout, cin, dtype, split, wp.data_ptr(), nbytes,
                                   bp.data_ptr(), _stream()), "sr355_pack_weight")
     return wp, bp
 
 
 @pack_weight.register_fake
-def _(w, bias, dtype):
+def _(w, bias, dtype, split=0):
     cout, cin = w.shape[0], w.shape[1]
     cpu = UNIT_CHANNELS[dtype]
-    cu = ((cin + cpu - 1) // cpu + 1) // 2 * 2
+    cu = (((2 * cin if split == 2 else cin) + cpu - 1) // cpu + 1) // 2 * 2 * (2 if split else 1)
     cp = (cout + 31) // 32 * 32
     return (w.new_empty(cu * 9 * cp * 16, dtype=torch.uint8), w.new_empty(cp, dtype=torch.float32))
 
@@ -112,7 +116,7 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
                 lrelu_slope: float, upsample: int,
                 res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
                 out_act: Optional[Tensor], out_unit_off: int,
-                out_f32: Optional[Tensor], out_nchw: Optional[Tensor]) -> None:
+                out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0) -> None:
     """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, scaled
     skips and optional nearest-x2 upsample of the input; writes any subset of the three outputs."""
     _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw)
@@ -133,6 +137,7 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
         raise RuntimeError(f"conv3x3_fwd: input {tuple(in_buf.shape)} does not match output N={N} H={H} W={W} "
                            f"upsample={upsample}")
     a.w_packed_dev, a.w_packed_bytes = w_packed.data_ptr(), _nbytes(w_packed)
+    a.weight_split = int(weight_split)
     a.bias_packed_dev = bias_packed.data_ptr()
     a.cout, a.lrelu_slope = int(cout), float(lrelu_slope)
     a.res1_dev, a.res1_scale = _ptr(res1), float(res1_scale)
@@ -150,15 +155,16 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
 
 @conv3x3_fwd.register_fake
 def _(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale, res2, res2_scale,
-      out_act, out_unit_off, out_f32, out_nchw):
+      out_act, out_unit_off, out_f32, out_nchw, weight_split=0):
     return None
 
 
 # ------------------------------------------------------------------------------------
 def make_cfg(cfg: List[int]) -> GeneratorCfg:
-    """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype]."""
+    """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype, hr_split]."""
     c = GeneratorCfg()
-    (c.in_channels, c.out_channels, c.num_features, c.num_blocks, c.growth_channels, c.dtype) = [int(v) for v in cfg]
+    (c.in_channels, c.out_channels, c.num_features, c.num_blocks, c.growth_channels, c.dtype,
+     c.hr_split) = [int(v) for v in cfg]
     c.trunk_fp32 = 1
     return c
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(L):
 
 def test_struct_sizes_match_header_layout():
     # natural alignment on x86-64: see sr355_conv_args / sr355_generator_cfg in include/sr355.h
-    assert C.sizeof(GeneratorCfg) == 7 * 4
+    assert C.sizeof(GeneratorCfg) == 8 * 4
     assert C.sizeof(ConvArgs) % 8 == 0 and C.sizeof(ConvArgs) >= 26 * 4
 
 
@@ -45,12 +45,16 @@ def test_size_queries(L):
     assert L.sr355_unit_channels(_lib.DTYPE_F32) == 4
     assert L.sr355_unit_channels(7) < 0
     # [cin_units][9][cout_pad][16 B]
-    assert L.sr355_packed_weight_bytes(32, 64, _lib.DTYPE_BF16) == 8 * 9 * 32 * 16
-    assert L.sr355_packed_weight_bytes(64, 192, _lib.DTYPE_BF16) == 24 * 9 * 64 * 16
-    assert L.sr355_packed_weight_bytes(3, 64, _lib.DTYPE_F32) == 16 * 9 * 32 * 16
-    assert L.sr355_packed_weight_bytes(64, 3, _lib.DTYPE_BF16) == 2 * 9 * 64 * 16
-    assert L.sr355_packed_weight_bytes(0, 3, _lib.DTYPE_BF16) == 0
-    cfg = GeneratorCfg(3, 3, 64, 23, 32, _lib.DTYPE_BF16, 1)
+    assert L.sr355_packed_weight_bytes(32, 64, _lib.DTYPE_BF16, 0) == 8 * 9 * 32 * 16
+    assert L.sr355_packed_weight_bytes(64, 192, _lib.DTYPE_BF16, 0) == 24 * 9 * 64 * 16
+    assert L.sr355_packed_weight_bytes(3, 64, _lib.DTYPE_F32, 0) == 16 * 9 * 32 * 16
+    assert L.sr355_packed_weight_bytes(64, 3, _lib.DTYPE_BF16, 0) == 2 * 9 * 64 * 16
+    assert L.sr355_packed_weight_bytes(0, 3, _lib.DTYPE_BF16, 0) == 0
+    # split modes append the residue image; input split counts 2*cin channels; bf16 only
+    assert L.sr355_packed_weight_bytes(64, 64, _lib.DTYPE_BF16, _lib.SPLIT_WEIGHT) == 2 * 8 * 9 * 64 * 16
+    assert L.sr355_packed_weight_bytes(64, 3, _lib.DTYPE_BF16, _lib.SPLIT_INPUT) == 2 * 2 * 9 * 64 * 16
+    assert L.sr355_packed_weight_bytes(64, 64, _lib.DTYPE_F32, _lib.SPLIT_WEIGHT) == 0
+    cfg = GeneratorCfg(3, 3, 64, 23, 32, _lib.DTYPE_BF16, 1, 1)
     assert L.sr355_generator_num_convs(C.byref(cfg)) == 351
     assert L.sr355_generator_packed_bytes(C.byref(cfg)) > 16697987 * 2
     small = L.sr355_generator_workspace_bytes(C.byref(cfg), 1, 16, 16)
@@ -60,7 +64,7 @@ def test_size_queries(L):
 
 
 def test_bad_arguments_are_rejected_without_touching_a_device(L):
-    bad = GeneratorCfg(3, 3, 60, 23, 32, _lib.DTYPE_BF16, 1)      # nf not a multiple of 16
+    bad = GeneratorCfg(3, 3, 60, 23, 32, _lib.DTYPE_BF16, 1, 1)      # nf not a multiple of 16
     assert L.sr355_generator_num_convs(C.byref(bad)) < 0
     assert b"multiples of 16" in L.sr355_last_error()
     assert L.sr355_generator_packed_bytes(C.byref(bad)) == 0
@@ -75,5 +79,5 @@ def test_bad_arguments_are_rejected_without_touching_a_device(L):
     assert b"input buffer" in L.sr355_last_error()
     a.upsample, a.H = 1, 7                                          # odd output under x2 upsample
     assert L.sr355_conv3x3_fwd(C.byref(a), None) == -1
-    cfg = GeneratorCfg(3, 3, 64, 1, 32, _lib.DTYPE_BF16, 1)
+    cfg = GeneratorCfg(3, 3, 64, 1, 32, _lib.DTYPE_BF16, 1, 0)
     assert L.sr355_generator_forward(C.byref(cfg), None, 0, None, None, 1, 8, 8, None, 0, None) == -1
