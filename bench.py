@@ -110,7 +110,7 @@ def roofline_from(rows):
         out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6,
                     "flop_per_launch": fl / cnt, "achieved": fl / sec / 1e12, "time_s": sec}
     dom = max(out, key=lambda s: out[s]["time_s"])
-    names = {"MB1": "conv3x3_mfma<bf16,MB=1,NB=4,SU=2> (Cout<=32)", "MB2": "conv3x3_mfma<bf16,MB=2,NB=4,SU=2> (Cout=64)"}
+    names = {"MB1": "conv3x3_ring<MB=1,NB=2,WAVES=4,R=3> (Cout<=32)", "MB2": "conv3x3_ring<MB=2,NB=2,WAVES=4,R=2> (Cout=64)"}
     d = out[dom]
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4), "traffic": None,

@@ -23,6 +23,8 @@
 // stages; stage s >= n_real re-reads input stage s - n_real against the residue weights, which
 // removes the weight-rounding error at twice the MFMA count.  Used for the four HR-side convs
 // and conv_first, whose weight rounding dominates the bf16 output error.
+#include <stdlib.h>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
         const int tx = p - ty * TWP;
         const int y = y0 - 1 + ty, x = x0 - 1 + tx;
         const bool valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-        goff[k] = valid ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : -1;
+        goff[k] = (valid && !(a.debug & 1)) ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : -1;
     }
     int woff[G::KW];
 #pragma unroll
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
         const int rem = j - u * 9 * G::CO;
         const int tap = rem / G::CO;
         const int co = rem - tap * G::CO;
-        woff[k] = (j < G::NWT) ? ((u * 9 + tap) * a.cout_pad + co) * 16 : 0;
+        woff[k] = (j < G::NWT && !(a.debug & 1)) ? ((u * 9 + tap) * a.cout_pad + co) * 16 : 0;
     }
 
     u32x4 sin[G::KIN], sw[G::KW];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = cb * G::CO + mb * 32 + q * 8 + h * 4;
-                if (c0 >= a.cout_real) continue;
+                if (c0 >= a.cout_real || (a.debug & 2)) continue;
                 const float4 bv = *reinterpret_cast<const float4 *>(a.bias + c0);
                 float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
                               acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
@@ -315,6 +317,15 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
     }
     b.n_real_stages = cin_units / 2;
     b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
+    static const int dbg = [] { const char *e = getenv("SR355_DEBUG"); return e ? atoi(e) : 0; }();
+    b.debug = dbg;
+    if (dtype == SR355_DTYPE_BF16 && (a.cout_pad == 32 || a.cout_pad == 64)) {
+        // Large images go to the persistent LDS-DMA ring kernel (one workgroup per CU needs at least
+        // a CU's worth of 16x32 tiles); SR355_RING=0/1 forces the choice for A/B measurements.
+        static const int force = [] { const char *e = getenv("SR355_RING"); return e ? atoi(e) : -1; }();
+        const long long tiles = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
+        if (force == 1 || (force != 0 && tiles >= 192)) return launch_conv3x3_ring(a, cin_units, weight_split, stream);
+    }
     const bool wide = (a.cout_pad % 64) == 0;
     if (dtype == SR355_DTYPE_BF16)
         return wide ? launch_nb<__bf16, 2, 2>(b, stream) : launch_nb<__bf16, 1, 2>(b, stream);

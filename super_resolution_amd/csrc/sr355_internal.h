@@ -30,6 +30,8 @@ struct ConvArgs {
     int cout_real, cout_pad;
     int f32_units;               // units per pixel of the fp32 trunk tensors (cout_real / 4)
     int tiles_x, tiles_y;
+    int rotate;                  // ring kernel: 1 = per-tile rotation of the stage order
+    int debug;                   // timing experiments only: bit 0 = skip reads, bit 1 = skip stores
 };
 
 void set_error(const char *fmt, ...);
@@ -37,6 +39,9 @@ int check_hip(hipError_t e, const char *what);
 
 // Launch the MFMA conv.  cin_units must be even; returns SR355_* code.
 int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split, hipStream_t stream);
+
+// Persistent LDS-DMA ring variant (bf16, large images); same contract as launch_conv3x3.
+int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipStream_t stream);
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
                            int dst_units, int split, hipStream_t stream);
