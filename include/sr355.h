@@ -49,7 +49,7 @@ extern "C" {
 #define SR355_SPLIT_WEIGHT 1
 #define SR355_SPLIT_INPUT 2
 
-#define SR355_ABI_VERSION 2
+#define SR355_ABI_VERSION 4
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -94,10 +94,16 @@ typedef struct sr355_conv_args {
     const float *bias_packed_dev;
     int cout;                  /* real output channels                                     */
     float lrelu_slope;         /* 1.0f = no activation                                     */
-    /* v = conv + bias; v = lrelu(v); if res1: v = res1 + res1_scale*v;
-     * if res2: v = res2 + res2_scale*v   (res*: fp32 trunk tensors, cout channels)       */
-    const float *res1_dev; float res1_scale;
-    const float *res2_dev; float res2_scale;
+    /* v = conv + bias; v = lrelu(v);
+     * if mask: v *= (mask > 0 ? 1 : mask_slope)   (mask: blocked activations of this dtype, read
+     *          at unit mask_unit_off: the LeakyReLU derivative in the backward pass);
+     * if res1: v = res1_weight*res1 + res1_scale*v;  if res2: v = res2_weight*res2 + res2_scale*v
+     * (res*: fp32 trunk tensors with cout channels)                                        */
+    const void *mask_dev; size_t mask_bytes;
+    int mask_units, mask_unit_off;
+    float mask_slope;
+    const float *res1_dev; float res1_weight, res1_scale;
+    const float *res2_dev; float res2_weight, res2_scale;
     size_t res_bytes;          /* size of each residual / out_f32 tensor                   */
     /* outputs (any subset, at least one) */
     void *out_act_dev;         /* blocked, dtype storage, written at out_unit_off          */
@@ -109,6 +115,49 @@ typedef struct sr355_conv_args {
 } sr355_conv_args;
 
 int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
+
+/* ---- backward pass of the convolution (autograd of esrgan_model.py:10-14 under
+ *      loss.backward(), /root/reference/esrgan/train.py:161, :220) ---- */
+
+/* Transposed packing for the data gradient: the forward weight w[cout][cin][3][3] contributes its
+ * `cout` output channels as INPUT units [unit_off, unit_off + ceil(cout/unit)) of a packed tensor
+ * with `packed_units` units and round_up(n_out, 32) output channels, which produce the forward
+ * input channels [ci_lo, ci_lo + n_out):  wt[c][o][tap] = scale * w[c][ci_lo + o][8 - tap].
+ * sr355_conv3x3_fwd run on the result (zero bias) IS the data-gradient convolution. */
+int sr355_pack_weight_transposed(const float *w_oihw_dev, int cout, int cin, int ci_lo, int n_out,
+                                 int dtype, float scale, void *w_packed_dev, int packed_units,
+                                 int unit_off, size_t w_packed_bytes, void *stream);
+
+/* Adjoint of the nearest x2 upsample fused in front of a conv: out[y][x] = sum of the 2x2 block of
+ * `in_dev` ([N][2H][units][2W] blocked), optionally gated by sign(mask) (LeakyReLU backward), written
+ * as fp32 trunk and/or blocked activations at out_unit_off. */
+int sr355_pool2x2_sum(const void *in_dev, size_t in_bytes, int N, int H, int W, int units, int dtype,
+                      const void *mask_dev, size_t mask_bytes, int mask_units, int mask_unit_off,
+                      float mask_slope, float *out_f32_dev, size_t out_f32_bytes, void *out_act_dev,
+                      size_t out_act_bytes, int out_units, int out_unit_off, void *stream);
+
+/* Weight and bias gradient (bf16 activations):
+ *   dw[co][ci][ky][kx] (=|+=) scale * sum_{n,y,x} dy[co][n,y,x] * in[ci][n, y+ky-1, x+kx-1]
+ *   db[co]             (=|+=) scale * sum_{n,y,x} dy[co][n,y,x]
+ * `in` is the conv's blocked input (upsample=1: stored at half resolution), `dy` the blocked
+ * gradient of its output at unit dy_unit_off.  Deterministic: per-workgroup partial slabs in
+ * `workspace_dev` are summed in a fixed order. */
+typedef struct sr355_wgrad_args {
+    int N, H, W;               /* output-resolution batch / height / width */
+    int upsample;
+    const void *in_dev; size_t in_bytes; int in_units;
+    int cin;                   /* real input channels (channels [0, cin) of `in`) */
+    const void *dy_dev; size_t dy_bytes; int dy_units, dy_unit_off;
+    int cout;                  /* <= 64 */
+    float scale;
+    int accumulate;            /* 0: overwrite dw/db, 1: add into them */
+    float *dw_dev; size_t dw_bytes;
+    float *db_dev;             /* may be NULL */
+    void *workspace_dev; size_t workspace_bytes;
+} sr355_wgrad_args;
+
+size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
+int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
 
 /* ---- whole generator (GeneratorRRDB.forward, esrgan_model.py:55-62) ---- */
 typedef struct sr355_generator_cfg {

@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 2
+ABI_VERSION = 4
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 
 # every symbol include/sr355.h declares
@@ -24,6 +24,7 @@ EXPORTS = (
     "sr355_nchw_to_blocked", "sr355_blocked_to_nchw",
     "sr355_packed_weight_bytes", "sr355_pack_weight",
     "sr355_conv3x3_fwd",
+    "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward",
 )
@@ -38,13 +39,27 @@ class ConvArgs(C.Structure):
         ("w_packed_dev", C.c_void_p), ("w_packed_bytes", C.c_size_t), ("weight_split", C.c_int),
         ("bias_packed_dev", C.c_void_p),
         ("cout", C.c_int), ("lrelu_slope", C.c_float),
-        ("res1_dev", C.c_void_p), ("res1_scale", C.c_float),
-        ("res2_dev", C.c_void_p), ("res2_scale", C.c_float),
+        ("mask_dev", C.c_void_p), ("mask_bytes", C.c_size_t),
+        ("mask_units", C.c_int), ("mask_unit_off", C.c_int), ("mask_slope", C.c_float),
+        ("res1_dev", C.c_void_p), ("res1_weight", C.c_float), ("res1_scale", C.c_float),
+        ("res2_dev", C.c_void_p), ("res2_weight", C.c_float), ("res2_scale", C.c_float),
         ("res_bytes", C.c_size_t),
         ("out_act_dev", C.c_void_p), ("out_act_bytes", C.c_size_t),
         ("out_units", C.c_int), ("out_unit_off", C.c_int),
         ("out_f32_dev", C.c_void_p),
         ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
+    ]
+
+
+class WgradArgs(C.Structure):
+    """Mirror of ``sr355_wgrad_args``."""
+    _fields_ = [
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("upsample", C.c_int),
+        ("in_dev", C.c_void_p), ("in_bytes", C.c_size_t), ("in_units", C.c_int), ("cin", C.c_int),
+        ("dy_dev", C.c_void_p), ("dy_bytes", C.c_size_t), ("dy_units", C.c_int), ("dy_unit_off", C.c_int),
+        ("cout", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
+        ("dw_dev", C.c_void_p), ("dw_bytes", C.c_size_t), ("db_dev", C.c_void_p),
+        ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -94,6 +109,11 @@ def lib() -> C.CDLL:
     L.sr355_packed_weight_bytes.restype = sz
     L.sr355_pack_weight.argtypes = [vp, vp, i, i, i, i, vp, sz, vp, vp]
     L.sr355_conv3x3_fwd.argtypes = [C.POINTER(ConvArgs), vp]
+    L.sr355_pack_weight_transposed.argtypes = [vp, i, i, i, i, i, f, vp, i, i, sz, vp]
+    L.sr355_pool2x2_sum.argtypes = [vp, sz, i, i, i, i, i, vp, sz, i, i, f, vp, sz, vp, sz, i, i, vp]
+    L.sr355_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
+    L.sr355_wgrad_workspace_bytes.restype = sz
+    L.sr355_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
     L.sr355_generator_num_convs.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.restype = sz

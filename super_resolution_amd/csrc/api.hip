@@ -219,6 +219,15 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
         set_error("conv3x3_fwd: packed weights/bias missing, misaligned, too small or bad split mode");
         return SR355_ERR_INVALID;
     }
+    if (p->mask_dev) {
+        const int units = (p->cout + cpu - 1) / cpu;
+        if (p->mask_unit_off < 0 || p->mask_unit_off + units > p->mask_units || !aligned16(p->mask_dev) ||
+            p->mask_bytes < (size_t)p->N * p->H * p->mask_units * p->W * 16 || (p->cout & 3)) {
+            set_error("conv3x3_fwd: mask geometry invalid (off=%d units=%d of %d)", p->mask_unit_off, units,
+                      p->mask_units);
+            return SR355_ERR_INVALID;
+        }
+    }
     if (!p->out_act_dev && !p->out_f32_dev && !p->out_nchw_dev) {
         set_error("conv3x3_fwd: no output requested");
         return SR355_ERR_INVALID;
@@ -263,6 +272,12 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     a.res2 = p->res2_dev;
     a.res1_scale = p->res1_scale;
     a.res2_scale = p->res2_scale;
+    a.res1_w = p->res1_weight;
+    a.res2_w = p->res2_weight;
+    a.mask_act = (const unsigned char *)p->mask_dev;
+    a.mask_units = p->mask_units;
+    a.mask_unit_off = p->mask_unit_off;
+    a.mask_slope = p->mask_slope;
     a.slope = p->lrelu_slope;
     a.N = p->N;
     a.H = p->H;
@@ -275,6 +290,89 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     a.cout_pad = cout_pad;
     a.f32_units = p->cout / 4;
     return launch_conv3x3(a, p->dtype, p->cin_units, p->weight_split != SR355_SPLIT_NONE, (hipStream_t)stream);
+}
+
+// ---- backward primitives ------------------------------------------------------------------
+int sr355_pack_weight_transposed(const float *w, int cout, int cin, int ci_lo, int n_out, int dtype, float scale,
+                                 void *wp, int packed_units, int unit_off, size_t wp_bytes, void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (cpu < 0 || !w || !wp || !aligned16(wp) || cout < 1 || cin < 1 || ci_lo < 0 || n_out < 1 ||
+        ci_lo + n_out > cin || unit_off < 0 || unit_off + (cout + cpu - 1) / cpu > packed_units ||
+        wp_bytes < (size_t)packed_units * 9 * cout_pad_for(n_out) * 16) {
+        set_error("pack_weight_transposed: bad arguments (cout=%d cin=%d ci_lo=%d n_out=%d units=%d off=%d)", cout,
+                  cin, ci_lo, n_out, packed_units, unit_off);
+        return SR355_ERR_INVALID;
+    }
+    return launch_pack_weight_t(w, cout, cin, ci_lo, n_out, dtype, scale, wp, unit_off, cout_pad_for(n_out),
+                                (hipStream_t)stream);
+}
+
+int sr355_pool2x2_sum(const void *in, size_t in_bytes, int N, int H, int W, int units, int dtype, const void *mask,
+                      size_t mask_bytes, int mask_units, int mask_unit_off, float mask_slope, float *out_f32,
+                      size_t out_f32_bytes, void *out_act, size_t out_act_bytes, int out_units, int out_unit_off,
+                      void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (cpu < 0 || !in || !aligned16(in) || N < 1 || H < 1 || W < 1 || units < 1 ||
+        in_bytes < (size_t)N * 4 * H * W * units * 16 || (!out_f32 && !out_act)) {
+        set_error("pool2x2_sum: bad arguments (N=%d H=%d W=%d units=%d)", N, H, W, units);
+        return SR355_ERR_INVALID;
+    }
+    if (mask && (mask_unit_off < 0 || mask_unit_off + units > mask_units || !aligned16(mask) ||
+                 mask_bytes < (size_t)N * H * W * mask_units * 16)) {
+        set_error("pool2x2_sum: mask geometry invalid");
+        return SR355_ERR_INVALID;
+    }
+    if (out_f32 && (!aligned16(out_f32) || out_f32_bytes < (size_t)N * H * W * units * cpu * 4)) {
+        set_error("pool2x2_sum: fp32 output too small");
+        return SR355_ERR_INVALID;
+    }
+    if (out_act && (out_unit_off < 0 || out_unit_off + units > out_units || !aligned16(out_act) ||
+                    out_act_bytes < (size_t)N * H * W * out_units * 16)) {
+        set_error("pool2x2_sum: activation output geometry invalid");
+        return SR355_ERR_INVALID;
+    }
+    return launch_pool2x2(in, N, H, W, units, dtype, mask, mask_units, mask_unit_off, mask_slope, out_f32, out_act,
+                          out_units, out_unit_off, (hipStream_t)stream);
+}
+
+size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
+    if (cout < 1 || cout > 64 || cin < 1 || N < 1 || H < 1 || W < 1) return 0;
+    return wgrad_workspace_bytes(cout, cin, N, H, W);
+}
+
+int sr355_conv3x3_wgrad(const sr355_wgrad_args *p, void *stream) {
+    if (!p) {
+        set_error("conv3x3_wgrad: args is null");
+        return SR355_ERR_INVALID;
+    }
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || p->cout > 64 || p->cin < 1 ||
+        (p->upsample != 0 && p->upsample != 1) || (p->upsample && ((p->H | p->W) & 1))) {
+        set_error("conv3x3_wgrad: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d", p->N, p->H, p->W, p->cout,
+                  p->cin, p->upsample);
+        return SR355_ERR_INVALID;
+    }
+    const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
+    const size_t in_img = (size_t)Hin * p->in_units * Win * 16, dy_img = (size_t)p->H * p->dy_units * p->W * 16;
+    if (in_img >= ((size_t)1 << 31) || dy_img >= ((size_t)1 << 31)) {
+        set_error("conv3x3_wgrad: one image exceeds the 31-bit offsets of the kernel");
+        return SR355_ERR_UNSUPPORTED;
+    }
+    if (!p->in_dev || !aligned16(p->in_dev) || p->in_bytes < in_img * p->N || (p->cin + 7) / 8 > p->in_units ||
+        !p->dy_dev || !aligned16(p->dy_dev) || p->dy_bytes < dy_img * p->N || p->dy_unit_off < 0 ||
+        p->dy_unit_off + (p->cout + 7) / 8 > p->dy_units) {
+        set_error("conv3x3_wgrad: input / gradient buffers missing, misaligned, too small or out of range");
+        return SR355_ERR_INVALID;
+    }
+    if (!p->dw_dev || p->dw_bytes < (size_t)p->cout * p->cin * 9 * 4 || !p->workspace_dev ||
+        !aligned16(p->workspace_dev) ||
+        p->workspace_bytes < wgrad_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W)) {
+        set_error("conv3x3_wgrad: dw or workspace missing / too small (need %zu workspace bytes)",
+                  wgrad_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W));
+        return SR355_ERR_INVALID;
+    }
+    return launch_wgrad3x3(p->in_dev, p->in_units, p->upsample, p->dy_dev, p->dy_units, p->dy_unit_off, p->N, p->H,
+                           p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev, p->db_dev,
+                           (float *)p->workspace_dev, (hipStream_t)stream);
 }
 
 // ---- generator ----------------------------------------------------------------------------
@@ -369,6 +467,8 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
         a.res2 = res2;
         a.res1_scale = s1;
         a.res2_scale = s2;
+        a.res1_w = 1.f;
+        a.res2_w = 1.f;
         a.slope = slope;
         a.N = N;
         a.H = h;

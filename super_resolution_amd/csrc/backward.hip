@@ -1,0 +1,459 @@
+// Backward-pass kernels of the 3x3 convolution (autograd of nn.Conv2d in
+// /root/reference/esrgan/models/esrgan_model.py:10-14 as driven by loss.backward() in
+// /root/reference/esrgan/train.py:161, :220).
+//
+// * data gradient: the forward MFMA kernels run it unchanged on TRANSPOSED packed weights
+//   (pack_weight_t below: input/output channels swapped, taps mirrored); a dense block's five data
+//   gradients read a growing stack of gradient channels exactly as its forward convs read a growing
+//   stack of activations, so no read-modify-write accumulation is needed;
+// * weight gradient: dW[co][ci][tap] = sum_pixels dY[co][p] * X[ci][p + tap] contracts over pixels,
+//   so both MFMA operands must hold 8 consecutive pixels of one channel per lane.  The LDS images
+//   stay pixel-major ([unit][pixel][8 channels], filled by LDS-DMA like the forward) and the
+//   fragments are fetched with the transposing read ds_read_b64_tr_b16;
+// * partial weight gradients of different pixel ranges go to per-workgroup slabs (plain stores) and
+//   a second kernel sums them in a fixed order: deterministic, no float atomics;
+// * 2x2 sum pooling: the adjoint of the nearest x2 upsample fused in front of upconv1/upconv2.
+#include "sr355_internal.h"
+
+namespace sr355 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 cvt<__bf16>(float v) { return (__bf16)v; }
+
+// ------------------------------------------------------------------------------------------
+// Transposed packing.  Forward weight w[Co][Ci][3][3]; the data-gradient conv takes the Co forward
+// outputs as its input channels and produces the forward input channels [ci_lo, ci_lo + n_out):
+//   wt[c'][o'][tap'] = scale * w[c'][ci_lo + o'][8 - tap'].
+// The destination is a packed tensor [units][9][cout_pad][unit]; this call fills units
+// [unit_off, unit_off + ceil(Co / unit)).
+template <typename T>
+__global__ void pack_weight_t_kernel(const float *__restrict__ w, T *__restrict__ wp, int Co, int Ci, int ci_lo,
+                                     int n_out, int unit_off, int cout_pad, float scale) {
+    constexpr int CPU = 16 / sizeof(T);
+    const int units = (Co + CPU - 1) / CPU;
+    const int total = units * 9 * cout_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i % cout_pad;
+        const int t = i / cout_pad;
+        const int tap = t % 9;
+        const int u = t / 9;
+        T v[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) {
+            const int c = u * CPU + e;
+            float f = 0.f;
+            if (c < Co && o < n_out) f = scale * w[((size_t)c * Ci + ci_lo + o) * 9 + (8 - tap)];
+            v[e] = cvt<T>(f);
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(wp)[((size_t)(unit_off + u) * 9 + tap) * cout_pad + o] = pk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[n][y][c][x] = sum of the 2x2 block of in at (2y.., 2x..), optionally gated by the sign of a
+// forward activation; written as fp32 trunk and/or as blocked activations at a unit offset.
+template <typename T>
+__global__ void pool2x2_kernel(const T *__restrict__ in, int N, int H, int W, int U, const T *__restrict__ mask,
+                               int mask_units, int mask_unit_off, float mask_slope, float *__restrict__ out_f32,
+                               T *__restrict__ out_act, int out_units, int out_unit_off) {
+    constexpr int CPU = 16 / sizeof(T);
+    const size_t total = (size_t)N * H * U * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t t = i / W;
+        const int u = (int)(t % U);
+        t /= U;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const size_t src = ((((size_t)n * 2 * H + 2 * y + dy) * U + u) * 2 * W + 2 * x + dx);
+                uint4 pk = reinterpret_cast<const uint4 *>(in)[src];
+                T v[CPU];
+                __builtin_memcpy(v, &pk, 16);
+#pragma unroll
+                for (int e = 0; e < CPU; ++e) acc[e] += (float)v[e];
+            }
+        if (mask) {
+            const size_t m = ((((size_t)n * H + y) * mask_units + mask_unit_off + u) * W + x);
+            uint4 pk = reinterpret_cast<const uint4 *>(mask)[m];
+            T v[CPU];
+            __builtin_memcpy(v, &pk, 16);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) acc[e] = (float)v[e] > 0.f ? acc[e] : acc[e] * mask_slope;
+        }
+        if (out_f32) {
+            constexpr int Q = CPU / 4;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const size_t o = ((((size_t)n * H + y) * (U * Q) + u * Q + q) * W + x);
+                reinterpret_cast<float4 *>(out_f32)[o] =
+                    make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        if (out_act) {
+            T v[CPU];
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) v[e] = cvt<T>(acc[e]);
+            uint4 pk;
+            __builtin_memcpy(&pk, v, 16);
+            const size_t o = ((((size_t)n * H + y) * out_units + out_unit_off + u) * W + x);
+            reinterpret_cast<uint4 *>(out_act)[o] = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient.  Workgroup = 3 waves; wave ky owns the three taps of kernel row ky.  Work item =
+// (4 x 32 pixel tile, chunk of 32 input channels); a workgroup sums its items in registers and
+// writes one slab [9][CO][32] at the end.
+struct WgradArgs {
+    const unsigned char *in;   // blocked bf16 activations (conv input)
+    const unsigned char *dy;   // blocked bf16 gradient of the conv output
+    float *slabs;              // [chunks][G][9][CO][32]
+    int N, H, W;               // output-resolution dims
+    int in_units, ups;         // input geometry (ups: input at half resolution, nearest x2)
+    int dy_units, dy_unit_off;
+    int tiles_x, tiles_y;
+};
+
+namespace {
+constexpr int WTH = 4;                     // tile rows
+constexpr int WPX = WTH * 32;              // 128 output pixels
+constexpr int WIPX = (WTH + 2) * 34;       // 204 haloed input pixels
+constexpr int W_OOB = 0x7fffff00;
+template <int MB>
+struct WGeo {
+    static constexpr int CO = MB * 32;
+    static constexpr int DY_ITEMS = MB * 4 * WPX;          // 512 * MB
+    static constexpr int DY_I = DY_ITEMS / 64;
+    static constexpr int IN_ITEMS = 4 * WIPX;              // 816
+    static constexpr int IN_I = (IN_ITEMS + 63) / 64;      // 13
+    static constexpr int JTOT = DY_I + IN_I;
+    static constexpr int KMAX = (JTOT + 2) / 3;
+    static constexpr int IN_OFF = DY_I * 1024;
+    static constexpr int STAGE_BYTES = JTOT * 1024;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+};
+}  // namespace
+
+// Two transposing reads = one MFMA operand: 8 consecutive pixels (rows of the LDS image) of the channel
+// this lane owns.  `p` is this lane's piece address (pixel q, channels 4p..4p+3) for the first 4 pixels.
+__device__ __forceinline__ bf16x8 read_tr_operand(const unsigned char *p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * 16));
+    bf16x8 f;
+    __builtin_memcpy(&f, &lo, 8);
+    __builtin_memcpy(reinterpret_cast<char *>(&f) + 8, &hi, 8);
+    return f;
+}
+
+template <int MB>
+__device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
+    typedef WGeo<MB> G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = ky
+    const int chunk = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const int Win = W >> a.ups;
+    const int in_img_bytes = (H >> a.ups) * a.in_units * Win * 16;
+    const int dy_img_bytes = H * a.dy_units * W * 16;
+    const int n_tiles = a.N * a.tiles_y * a.tiles_x;
+    const int nwg = gridDim.x;
+
+    int voff[G::KMAX];
+    __amdgpu_buffer_rsrc_t in_rsrc, dy_rsrc;
+    in_rsrc = dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in), 0, 0, 0x00020000);
+#define SR355_WG_SETUP(T_)                                                                              \
+    {                                                                                                   \
+        const int txi = (T_) % a.tiles_x;                                                               \
+        const int tr = (T_) / a.tiles_x;                                                                \
+        const int tyi = tr % a.tiles_y;                                                                 \
+        const int n = tr / a.tiles_y;                                                                   \
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in) + (size_t)n * in_img_bytes, 0, \
+                                                    in_img_bytes, 0x00020000);                          \
+        dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.dy) + (size_t)n * dy_img_bytes, 0, \
+                                                    dy_img_bytes, 0x00020000);                          \
+        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
+            const int j = k * 3 + wave;                                                                 \
+            voff[k] = W_OOB;                                                                            \
+            if (j < G::DY_I) {                                                                          \
+                const int i = j * 64 + lane; /* [u][py][px] */                                          \
+                const int u = i / WPX;                                                                  \
+                const int p = i - u * WPX;                                                              \
+                const int y = tyi * WTH + (p >> 5), x = txi * 32 + (p & 31);                            \
+                if (y < H && x < W) voff[k] = ((y * a.dy_units + a.dy_unit_off + u) * W + x) * 16;      \
+            } else if (j < G::JTOT) {                                                                   \
+                const int i = (j - G::DY_I) * 64 + lane; /* [u][ty][tx] haloed */                       \
+                const int u = i / WIPX;                                                                 \
+                const int p = i - u * WIPX;                                                             \
+                const int ty = p / 34;                                                                  \
+                const int tx = p - ty * 34;                                                             \
+                const int y = tyi * WTH - 1 + ty, x = txi * 32 - 1 + tx;                                \
+                const int uu = chunk * 4 + u;                                                           \
+                if (i < G::IN_ITEMS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && uu < a.in_units) \
+                    voff[k] = (((y >> a.ups) * a.in_units + uu) * Win + (x >> a.ups)) * 16;             \
+            }                                                                                           \
+        }                                                                                               \
+    }
+#define SR355_WG_ISSUE(SLOT)                                                                            \
+    {                                                                                                   \
+        unsigned char *dst = smem + (SLOT) * G::STAGE_BYTES;                                            \
+        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
+            const int j = k * 3 + wave;                                                                 \
+            if (j < G::JTOT) {                                                                          \
+                lds_void *l = (lds_void *)(dst + j * 1024);                                             \
+                if (j < G::DY_I)                                                                        \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, l, 16, voff[k], 0, 0, 0);         \
+                else                                                                                    \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l, 16, voff[k], 0, 0, 0);         \
+            }                                                                                           \
+        }                                                                                               \
+    }
+
+    f32x16 acc[3][MB];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kx][mb][e] = 0.f;
+
+    // transposing-read lane geometry: 16-lane group g reads a 4-pixel x 16-channel block; lane 4q+p of
+    // the group supplies the address of pixel q, channels 4p..4p+3, and receives channel (lane & 15).
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int ch_half = g & 1, k_half = g >> 1;
+    const int unit_in_block = 2 * ch_half + (p >> 1);          // of the 4 units of a 32-channel block
+    const int byte_in_unit = (p & 1) * 8;
+    const int dy_lane = (unit_in_block * WPX + 8 * k_half + q) * 16 + byte_in_unit;
+    const int in_lane = G::IN_OFF + (unit_in_block * WIPX + wave * 34 + 8 * k_half + q) * 16 + byte_in_unit;
+
+    int t = blockIdx.x;
+    int slot = 0;
+    if (t < n_tiles) {
+        SR355_WG_SETUP(t);
+        SR355_WG_ISSUE(0);
+    }
+    for (; t < n_tiles; t += nwg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + nwg < n_tiles) {
+            SR355_WG_SETUP(t + nwg);
+            SR355_WG_ISSUE(slot ^ 1);
+        }
+        const unsigned char *buf = smem + slot * G::STAGE_BYTES;
+#pragma unroll
+        for (int y = 0; y < WTH; ++y) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[MB], bfr[3];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    af[mb] = read_tr_operand(buf + dy_lane + (mb * 4 * WPX + y * 32 + 16 * s) * 16);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    bfr[kx] = read_tr_operand(buf + in_lane + (y * 34 + 16 * s + kx) * 16);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[kx][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[kx], acc[kx][mb], 0, 0, 0);
+            }
+        }
+        slot ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // slab [tap][co][ci32]; accumulator element: row (co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (ci) = lane&31
+    float *slab = a.slabs + ((size_t)chunk * nwg + blockIdx.x) * 9 * G::CO * 32;
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowc = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                slab[((wave * 3 + kx) * G::CO + rowc) * 32 + col] = acc[kx][mb][e];
+            }
+}
+
+#undef SR355_WG_SETUP
+#undef SR355_WG_ISSUE
+
+// Non-template entry points: hipcc (ROCm 7.2) emits no host stub for a kernel TEMPLATE whose body
+// issues LDS-DMA loads through two run-time selected descriptors; plain kernels are unaffected.
+__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb1(const WgradArgs a) { wgrad3x3_body<1>(a); }
+__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { wgrad3x3_body<2>(a); }
+
+// dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int cout, int cin, int CO,
+                                    int G, float scale, int accumulate) {
+    const int total = 9 * cout * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin;
+        const int t = i / cin;
+        const int co = t % cout;
+        const int tap = t / cout;
+        const float *s = slabs + ((size_t)(ci >> 5) * G * 9 + tap) * CO * 32 + co * 32 + (ci & 31);
+        float sum = 0.f;
+        for (int gidx = 0; gidx < G; ++gidx) sum += s[(size_t)gidx * 9 * CO * 32];
+        float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
+        *d = accumulate ? *d + scale * sum : scale * sum;
+    }
+}
+
+// db[c] (=|+=) scale * sum over pixels of dy[c]; one workgroup per unit of 8 channels.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const __bf16 *__restrict__ dy, int N, int H, int W, int dy_units,
+                                                         int dy_unit_off, int cout, float scale, float *__restrict__ db,
+                                                         int accumulate) {
+    __shared__ float red[256][8];
+    const int u = blockIdx.x;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t rows = (size_t)N * H;
+    for (size_t rr = threadIdx.x / 32; rr < rows; rr += 8) {
+        const __bf16 *base = dy + ((rr * dy_units + dy_unit_off + u) * W) * 8;
+        for (int x = threadIdx.x % 32; x < W; x += 32) {
+            uint4 pk = reinterpret_cast<const uint4 *>(base)[x];
+            __bf16 v[8];
+            __builtin_memcpy(v, &pk, 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + s][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) {
+        const int c = u * 8 + threadIdx.x;
+        if (c < cout) db[c] = accumulate ? db[c] + scale * red[0][threadIdx.x] : scale * red[0][threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static unsigned grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_pack_weight_t(const float *w, int Co, int Ci, int ci_lo, int n_out, int dtype, float scale, void *wp,
+                         int unit_off, int cout_pad, hipStream_t stream) {
+    const int cpu = unit_channels(dtype);
+    const size_t total = (size_t)((Co + cpu - 1) / cpu) * 9 * cout_pad;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_t_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, w, (__bf16 *)wp,
+                           Co, Ci, ci_lo, n_out, unit_off, cout_pad, scale);
+    else
+        hipLaunchKernelGGL(pack_weight_t_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, (float *)wp, Co,
+                           Ci, ci_lo, n_out, unit_off, cout_pad, scale);
+    return check_hip(hipGetLastError(), "pack_weight_t launch");
+}
+
+int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const void *mask, int mask_units,
+                   int mask_unit_off, float mask_slope, float *out_f32, void *out_act, int out_units, int out_unit_off,
+                   hipStream_t stream) {
+    const size_t total = (size_t)N * H * U * W;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(pool2x2_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16 *)in, N, H,
+                           W, U, (const __bf16 *)mask, mask_units, mask_unit_off, mask_slope, out_f32,
+                           (__bf16 *)out_act, out_units, out_unit_off);
+    else
+        hipLaunchKernelGGL(pool2x2_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float *)in, N, H, W,
+                           U, (const float *)mask, mask_units, mask_unit_off, mask_slope, out_f32, (float *)out_act,
+                           out_units, out_unit_off);
+    return check_hip(hipGetLastError(), "pool2x2 launch");
+}
+
+// Slab geometry of a weight-gradient launch: chunks of 32 input channels x G pixel-range workgroups.
+void wgrad_geometry(int cin, int N, int H, int W, int *chunks, int *G) {
+    const int cin_units = (cin + 7) / 8;
+    *chunks = (cin_units + 3) / 4;
+    const long long tiles = (long long)N * ((H + WTH - 1) / WTH) * ((W + 31) / 32);
+    long long g = tiles / 4;
+    const long long cap = 768 / *chunks;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    *G = (int)g;
+}
+
+size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
+    int chunks, G;
+    wgrad_geometry(cin, N, H, W, &chunks, &G);
+    return (size_t)chunks * G * 9 * cout_pad_for(cout) * 32 * sizeof(float);
+}
+
+int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
+                    int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
+                    hipStream_t stream) {
+    const int co_pad = cout_pad_for(cout);
+    if (co_pad != 32 && co_pad != 64) {
+        set_error("wgrad3x3: cout=%d not supported (needs <= 64 output channels)", cout);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    int chunks, G;
+    wgrad_geometry(cin, N, H, W, &chunks, &G);
+    WgradArgs a;
+    a.in = (const unsigned char *)in;
+    a.dy = (const unsigned char *)dy;
+    a.slabs = slabs;
+    a.N = N, a.H = H, a.W = W;
+    a.in_units = in_units, a.ups = ups;
+    a.dy_units = dy_units, a.dy_unit_off = dy_unit_off;
+    a.tiles_x = (W + 31) / 32;
+    a.tiles_y = (H + WTH - 1) / WTH;
+    static bool attr_done[2][64] = {};
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+    if (dev < 0 || dev >= 64) dev = 0;
+    const int mbi = co_pad == 64 ? 1 : 0;
+    if (!attr_done[mbi][dev]) {
+        hipError_t e = mbi ? hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb2),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<2>::LDS_BYTES)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb1),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<1>::LDS_BYTES);
+        if (check_hip(e, "hipFuncSetAttribute")) return SR355_ERR_HIP;
+        attr_done[mbi][dev] = true;
+    }
+    dim3 grid(G, chunks, 1);
+    if (mbi)
+        hipLaunchKernelGGL(wgrad3x3_kernel_mb2, grid, dim3(192), WGeo<2>::LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL(wgrad3x3_kernel_mb1, grid, dim3(192), WGeo<1>::LDS_BYTES, stream, a);
+    if (check_hip(hipGetLastError(), "wgrad3x3 launch")) return SR355_ERR_HIP;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)9 * cout * cin)), dim3(256), 0, stream, slabs, dw,
+                       cout, cin, co_pad, G, scale, accumulate);
+    if (check_hip(hipGetLastError(), "wgrad reduce launch")) return SR355_ERR_HIP;
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_kernel, dim3((cout + 7) / 8), dim3(256), 0, stream, (const __bf16 *)dy, N, H, W,
+                           dy_units, dy_unit_off, cout, scale, db, accumulate);
+        if (check_hip(hipGetLastError(), "bias grad launch")) return SR355_ERR_HIP;
+    }
+    return SR355_OK;
+}
+
+}  // namespace sr355

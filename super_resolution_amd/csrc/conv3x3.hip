@@ -25,6 +25,7 @@
 // and conv_first, whose weight rounding dominates the bf16 output error.
 #include <stdlib.h>
 
+#include "conv_epilogue.h"
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -205,62 +206,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias, LeakyReLU, scaled skips, stores ----
+    // ---- epilogue: bias, LeakyReLU, mask, scaled skips, stores ----
     const int x = x0 + r;
-    if (x >= W) return;
-    const float slope = a.slope;
+    if (x >= W || (a.debug & 2)) return;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int y = y0 + wave * NB + nb;
         if (y >= H) continue;
-        const size_t row = (size_t)n * H + y;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = cb * G::CO + mb * 32 + q * 8 + h * 4;
-                if (c0 >= a.cout_real || (a.debug & 2)) continue;
+                if (c0 >= a.cout_real) continue;
                 const float4 bv = *reinterpret_cast<const float4 *>(a.bias + c0);
                 float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
                               acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-                const size_t fidx = (row * a.f32_units + (c0 >> 2)) * W + x;  // in float4 units
-                if (a.res1) {
-                    const float4 rv = reinterpret_cast<const float4 *>(a.res1)[fidx];
-                    v[0] = rv.x + a.res1_scale * v[0];
-                    v[1] = rv.y + a.res1_scale * v[1];
-                    v[2] = rv.z + a.res1_scale * v[2];
-                    v[3] = rv.w + a.res1_scale * v[3];
-                }
-                if (a.res2) {
-                    const float4 rv = reinterpret_cast<const float4 *>(a.res2)[fidx];
-                    v[0] = rv.x + a.res2_scale * v[0];
-                    v[1] = rv.y + a.res2_scale * v[1];
-                    v[2] = rv.z + a.res2_scale * v[2];
-                    v[3] = rv.w + a.res2_scale * v[3];
-                }
-                if (a.out_f32) reinterpret_cast<float4 *>(a.out_f32)[fidx] = make_float4(v[0], v[1], v[2], v[3]);
-                if (a.out_act) {
-                    if constexpr (sizeof(T) == 2) {
-                        const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 3)) * W + x) * 16 + h * 8;
-                        bf16x4 pk;
-                        pk[0] = (__bf16)v[0];
-                        pk[1] = (__bf16)v[1];
-                        pk[2] = (__bf16)v[2];
-                        pk[3] = (__bf16)v[3];
-                        *reinterpret_cast<bf16x4 *>(a.out_act + o) = pk;
-                    } else {
-                        const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 2)) * W + x) * 16;
-                        *reinterpret_cast<float4 *>(a.out_act + o) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-                if (a.out_nchw) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c0 + j < a.cout_real)
-                            a.out_nchw[(((size_t)n * a.cout_real + c0 + j) * H + y) * W + x] = v[j];
-                }
+                conv_epilogue_quad<T>(a, v, n, y, x, c0, h);
             }
         }
     }

@@ -14,6 +14,7 @@
 // Replaces nn.Conv2d + cat + LeakyReLU + skips of /root/reference/esrgan/models/esrgan_model.py:18-24.
 #include <stdlib.h>
 
+#include "conv_epilogue.h"
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -231,12 +232,10 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
             const int ty_i = tr % a.tiles_y;
             const int n = tr / a.tiles_y;
             const int x = tx_i * 32 + r;
-            const float slope = a.slope;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int y = ty_i * G::TH + wave * NB + nb;
                 const bool ok = (x < W) && (y < H) && !(a.debug & 2);
-                const size_t row = (size_t)n * H + y;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -247,43 +246,9 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
                         float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
                                       acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[mb][nb][4 * q + e] = 0.f;
-                            v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-                        }
+                        for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
                         if (!ok || c0 >= a.cout_real) continue;
-                        const size_t fidx = (row * a.f32_units + (c0 >> 2)) * W + x;
-                        if (a.res1) {
-                            const float4 rv = reinterpret_cast<const float4 *>(a.res1)[fidx];
-                            v[0] = rv.x + a.res1_scale * v[0];
-                            v[1] = rv.y + a.res1_scale * v[1];
-                            v[2] = rv.z + a.res1_scale * v[2];
-                            v[3] = rv.w + a.res1_scale * v[3];
-                        }
-                        if (a.res2) {
-                            const float4 rv = reinterpret_cast<const float4 *>(a.res2)[fidx];
-                            v[0] = rv.x + a.res2_scale * v[0];
-                            v[1] = rv.y + a.res2_scale * v[1];
-                            v[2] = rv.z + a.res2_scale * v[2];
-                            v[3] = rv.w + a.res2_scale * v[3];
-                        }
-                        if (a.out_f32)
-                            reinterpret_cast<float4 *>(a.out_f32)[fidx] = make_float4(v[0], v[1], v[2], v[3]);
-                        if (a.out_act) {
-                            const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 3)) * W + x) * 16 + h * 8;
-                            bf16x4 pk;
-                            pk[0] = (__bf16)v[0];
-                            pk[1] = (__bf16)v[1];
-                            pk[2] = (__bf16)v[2];
-                            pk[3] = (__bf16)v[3];
-                            *reinterpret_cast<bf16x4 *>(a.out_act + o) = pk;
-                        }
-                        if (a.out_nchw) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (c0 + e < a.cout_real)
-                                    a.out_nchw[(((size_t)n * a.cout_real + c0 + e) * H + y) * W + x] = v[e];
-                        }
+                        conv_epilogue_quad<__bf16>(a, v, n, y, x, c0, h);
                     }
                 }
             }

@@ -19,7 +19,11 @@ struct ConvArgs {
     float *out_nchw;             // [N][cout_real][H][W], may be null
     const float *res1;           // fp32 trunk, may be null
     const float *res2;           // fp32 trunk, may be null
-    float res1_scale, res2_scale;
+    float res1_scale, res2_scale; // v = resK_w * resK + resK_scale * v
+    float res1_w, res2_w;
+    const unsigned char *mask_act; // blocked activations whose sign gates v (LeakyReLU backward), may be null
+    int mask_units, mask_unit_off;
+    float mask_slope;
     float slope;                 // LeakyReLU slope, 1.0f = identity
     int N, H, W;                 // output dims
     int in_units;                // units per pixel of the input buffer
@@ -49,6 +53,17 @@ int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dty
                            int H, int W, float *dst, hipStream_t stream);
 int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,
                        void *wp, float *bp, hipStream_t stream);
+
+// ---- backward.hip ----
+int launch_pack_weight_t(const float *w, int Co, int Ci, int ci_lo, int n_out, int dtype, float scale, void *wp,
+                         int unit_off, int cout_pad, hipStream_t stream);
+int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const void *mask, int mask_units,
+                   int mask_unit_off, float mask_slope, float *out_f32, void *out_act, int out_units, int out_unit_off,
+                   hipStream_t stream);
+size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
+int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
+                    int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
+                    hipStream_t stream);
 
 inline int unit_channels(int dtype) { return dtype == SR355_DTYPE_BF16 ? 8 : dtype == SR355_DTYPE_F32 ? 4 : -1; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

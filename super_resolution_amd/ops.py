@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, GeneratorCfg, check
+from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, GeneratorCfg, WgradArgs, check
 
 _TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
 _CODE = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}
@@ -116,10 +116,12 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
                 lrelu_slope: float, upsample: int,
                 res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
                 out_act: Optional[Tensor], out_unit_off: int,
-                out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0) -> None:
-    """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, scaled
-    skips and optional nearest-x2 upsample of the input; writes any subset of the three outputs."""
-    _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw)
+                out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
+                mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
+                res1_weight: float = 1.0, res2_weight: float = 1.0) -> None:
+    """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, sign mask,
+    weighted skips and optional nearest-x2 upsample of the input; writes any subset of the outputs."""
+    _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw, mask)
     a = ConvArgs()
     a.dtype = _CODE[in_buf.dtype]
     if out_act is not None:
@@ -140,8 +142,11 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
     a.weight_split = int(weight_split)
     a.bias_packed_dev = bias_packed.data_ptr()
     a.cout, a.lrelu_slope = int(cout), float(lrelu_slope)
-    a.res1_dev, a.res1_scale = _ptr(res1), float(res1_scale)
-    a.res2_dev, a.res2_scale = _ptr(res2), float(res2_scale)
+    a.res1_dev, a.res1_weight, a.res1_scale = _ptr(res1), float(res1_weight), float(res1_scale)
+    a.res2_dev, a.res2_weight, a.res2_scale = _ptr(res2), float(res2_weight), float(res2_scale)
+    if mask is not None:
+        a.mask_dev, a.mask_bytes = mask.data_ptr(), _nbytes(mask)
+        a.mask_units, a.mask_unit_off, a.mask_slope = int(mask.shape[2]), int(mask_unit_off), float(mask_slope)
     sizes = [_nbytes(t) for t in (res1, res2, out_f32) if t is not None]
     a.res_bytes = min(sizes) if sizes else 0
     a.out_act_dev, a.out_act_bytes = _ptr(out_act), _nbytes(out_act)
@@ -155,7 +160,75 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
 
 @conv3x3_fwd.register_fake
 def _(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale, res2, res2_scale,
-      out_act, out_unit_off, out_f32, out_nchw, weight_split=0):
+      out_act, out_unit_off, out_f32, out_nchw, weight_split=0, mask=None, mask_unit_off=0, mask_slope=1.0,
+      res1_weight=1.0, res2_weight=1.0):
+    return None
+
+
+# ------------------------------------------------------------------------------------
+@torch.library.custom_op("sr355::pack_weight_transposed", mutates_args=("w_packed",))
+def pack_weight_transposed(w: Tensor, ci_lo: int, n_out: int, scale: float, w_packed: Tensor, packed_units: int,
+                           unit_off: int, dtype: int) -> None:
+    """Write the data-gradient (transposed, tap-mirrored) form of forward weight ``w`` into input units
+    [unit_off, ...) of ``w_packed``; see sr355_pack_weight_transposed in include/sr355.h."""
+    _need_cuda(w, w_packed)
+    with torch.cuda.device(w.device):
+        check(_lib.lib().sr355_pack_weight_transposed(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), ci_lo, n_out,
+                                                      dtype, float(scale), w_packed.data_ptr(), packed_units,
+                                                      unit_off, _nbytes(w_packed), _stream()),
+              "sr355_pack_weight_transposed")
+
+
+@pack_weight_transposed.register_fake
+def _(w, ci_lo, n_out, scale, w_packed, packed_units, unit_off, dtype):
+    return None
+
+
+@torch.library.custom_op("sr355::pool2x2_sum", mutates_args=("out_f32", "out_act"))
+def pool2x2_sum(x: Tensor, mask: Optional[Tensor], mask_unit_off: int, mask_slope: float,
+                out_f32: Optional[Tensor], out_act: Optional[Tensor], out_unit_off: int) -> None:
+    """Adjoint of nearest x2 upsampling on a blocked tensor [N,2H,U,2W,c], optionally sign-gated."""
+    _need_cuda(x, mask, out_f32, out_act)
+    N, H2, U, W2, _c = x.shape
+    with torch.cuda.device(x.device):
+        check(_lib.lib().sr355_pool2x2_sum(
+            x.data_ptr(), _nbytes(x), N, H2 // 2, W2 // 2, U, _CODE[x.dtype],
+            _ptr(mask), _nbytes(mask), int(mask.shape[2]) if mask is not None else 0, mask_unit_off, float(mask_slope),
+            _ptr(out_f32), _nbytes(out_f32), _ptr(out_act), _nbytes(out_act),
+            int(out_act.shape[2]) if out_act is not None else 0, out_unit_off, _stream()), "sr355_pool2x2_sum")
+
+
+@pool2x2_sum.register_fake
+def _(x, mask, mask_unit_off, mask_slope, out_f32, out_act, out_unit_off):
+    return None
+
+
+@torch.library.custom_op("sr355::conv3x3_wgrad", mutates_args=("dw", "db"))
+def conv3x3_wgrad(in_buf: Tensor, cin: int, upsample: int, dy: Tensor, dy_unit_off: int, cout: int, scale: float,
+                  accumulate: int, dw: Tensor, db: Optional[Tensor]) -> None:
+    """Weight / bias gradient of a 3x3 conv from its blocked bf16 input and output gradient."""
+    _need_cuda(in_buf, dy, dw, db)
+    if in_buf.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        raise RuntimeError("conv3x3_wgrad runs on bf16 activations")
+    a = WgradArgs()
+    N, H, _U, W, _c = dy.shape
+    a.N, a.H, a.W, a.upsample = int(N), int(H), int(W), int(upsample)
+    a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
+    a.dy_dev, a.dy_bytes, a.dy_units, a.dy_unit_off = dy.data_ptr(), _nbytes(dy), int(dy.shape[2]), int(dy_unit_off)
+    a.cout, a.scale, a.accumulate = int(cout), float(scale), int(accumulate)
+    a.dw_dev, a.dw_bytes, a.db_dev = dw.data_ptr(), _nbytes(dw), _ptr(db)
+    L = _lib.lib()
+    need = L.sr355_wgrad_workspace_bytes(cout, cin, N, H, W)
+    if need == 0:
+        raise RuntimeError("conv3x3_wgrad: unsupported shape")
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
+    a.workspace_dev, a.workspace_bytes = ws.data_ptr(), need
+    with torch.cuda.device(dy.device):
+        check(L.sr355_conv3x3_wgrad(C.byref(a), _stream()), "sr355_conv3x3_wgrad")
+
+
+@conv3x3_wgrad.register_fake
+def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
     return None
 
 

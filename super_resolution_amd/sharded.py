@@ -1,0 +1,65 @@
+"""Row-band sharding of one large image across ranks (one process per GPU).
+
+The reference runs the whole LR image through the generator in one call
+(/root/reference/esrgan/test.py:71-72).  Here the image is cut into horizontal bands, each
+extended by ``halo`` LR rows on its interior edges; every rank super-resolves its band, crops the
+``4*halo`` HR rows that only served as context, and rank 0 gathers the bands.  There is no
+collective inside the network: the only exchange is the final gather.
+
+The generator's receptive field is 347 stacked 3x3 convs, wider than any practical halo, so the
+result is an approximation whose error falls with ``halo`` (with default-initialised weights:
+halo 8 -> 5e-6 max-abs, halo 16 -> 1e-6); ``halo >= H`` reproduces the full-image result exactly.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+
+def band_edges(height: int, bands: int, halo: int) -> List[Tuple[int, int, int, int]]:
+    """(y0, y1, a, b) per band: rows [y0, y1) are owned, rows [a, b) are computed."""
+    if height < 1 or bands < 1 or halo < 0:
+        raise ValueError("height and bands must be positive, halo non-negative")
+    bands = min(bands, height)
+    cuts = [round(i * height / bands) for i in range(bands + 1)]
+    return [(cuts[i], cuts[i + 1], max(0, cuts[i] - halo), min(height, cuts[i + 1] + halo))
+            for i in range(bands)]
+
+
+def run_band(net: Callable[[Tensor], Tensor], x: Tensor, edge: Tuple[int, int, int, int], scale: int = 4) -> Tensor:
+    """Super-resolve rows [a, b) and return the HR rows belonging to [y0, y1)."""
+    y0, y1, a, b = edge
+    sr = net(x[:, :, a:b, :].contiguous())
+    top = scale * (y0 - a)
+    return sr[:, :, top: top + scale * (y1 - y0), :]
+
+
+def tiled_forward(net: Callable[[Tensor], Tensor], x: Tensor, bands: int, halo: int = 16, scale: int = 4) -> Tensor:
+    """All bands on the calling device, one after the other (bounds the activation memory)."""
+    return torch.cat([run_band(net, x, e, scale) for e in band_edges(x.shape[2], bands, halo)], dim=2)
+
+
+def sharded_forward(net: Callable[[Tensor], Tensor], x: Tensor, halo: int = 16, scale: int = 4,
+                    group=None, dst: int = 0, out_channels: int = 3) -> Optional[Tensor]:
+    """Each rank computes band ``rank`` of ``x`` (every rank holds the same LR image); rank ``dst``
+    returns the assembled HR image, the others ``None``.  Works with any backend (RCCL on GPUs)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    edges = band_edges(x.shape[2], world, halo)
+    N, W = x.shape[0], x.shape[3]
+    rows = max(scale * (e[1] - e[0]) for e in edges)
+    # gather needs equal shapes: pad every band to the tallest one (ranks beyond the row count send zeros)
+    padded = torch.zeros((N, out_channels, rows, scale * W), dtype=torch.float32, device=x.device)
+    if rank < len(edges):
+        mine = run_band(net, x, edges[rank], scale)
+        padded[:, :, : mine.shape[2]] = mine
+    bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = [bucket[i][:, :, : scale * (e[1] - e[0])] for i, e in enumerate(edges)]
+    return torch.cat(parts, dim=2)

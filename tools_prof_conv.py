@@ -36,7 +36,7 @@ def main():
         a.w_packed_dev, a.w_packed_bytes, a.weight_split = wp.data_ptr(), wp.numel(), 0
         a.bias_packed_dev, a.cout, a.lrelu_slope = bp.data_ptr(), cout, slope
         if res1 is not None:
-            a.res1_dev, a.res1_scale, a.res_bytes = res1.data_ptr(), 0.2, res1.numel() * 4
+            a.res1_dev, a.res1_weight, a.res1_scale, a.res_bytes = res1.data_ptr(), 1.0, 0.2, res1.numel() * 4
         a.out_act_dev, a.out_act_bytes, a.out_units, a.out_unit_off = out_act.data_ptr(), out_act.numel() * 2, 24, off
         if out_f32 is not None:
             a.out_f32_dev = out_f32.data_ptr()
