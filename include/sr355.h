@@ -49,7 +49,7 @@ extern "C" {
 #define SR355_SPLIT_WEIGHT 1
 #define SR355_SPLIT_INPUT 2
 
-#define SR355_ABI_VERSION 4
+#define SR355_ABI_VERSION 5
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -182,6 +182,31 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed_d
                             size_t packed_bytes, const float *in_nchw_dev, float *out_nchw_dev,
                             int N, int H, int W, void *workspace_dev, size_t workspace_bytes,
                             void *stream);
+
+/* ---- training: forward that keeps activations, and the backward pass (bf16 kernels only) ----
+ * Replaces what autograd records for GeneratorRRDB.forward and replays under loss.backward()
+ * (/root/reference/esrgan/train.py:159-161, :212-220). */
+size_t sr355_generator_saved_bytes(const sr355_generator_cfg *cfg, int N, int H, int W);
+size_t sr355_generator_train_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W);
+/* As sr355_generator_forward; `saved_dev` receives the activations the backward pass reads. */
+int sr355_generator_forward_train(const sr355_generator_cfg *cfg, const void *packed_dev,
+                                  size_t packed_bytes, const float *in_nchw_dev, float *out_nchw_dev,
+                                  int N, int H, int W, void *saved_dev, size_t saved_bytes,
+                                  void *workspace_dev, size_t workspace_bytes, void *stream);
+/* Transposed (data-gradient) form of every conv weight, from the same OIHW fp32 tensors. */
+size_t sr355_generator_packed_bwd_bytes(const sr355_generator_cfg *cfg);
+int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const *w_ptrs, int n_convs,
+                             void *packed_bwd_dev, size_t packed_bwd_bytes, void *stream);
+size_t sr355_generator_bwd_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W);
+/* Number of floats of the flat gradient buffer: per conv in state_dict order, weight then bias. */
+size_t sr355_generator_grads_floats(const sr355_generator_cfg *cfg);
+/* grad_out [N][out][4H][4W] fp32 -> grads_dev (every parameter gradient, overwritten) and, when
+ * grad_in_nchw_dev is not NULL, the gradient of the input [N][in][H][W]. */
+int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_bwd_dev,
+                             size_t packed_bwd_bytes, const void *saved_dev, size_t saved_bytes,
+                             const float *grad_out_nchw_dev, float *grads_dev, size_t grads_floats,
+                             float *grad_in_nchw_dev, int N, int H, int W, void *workspace_dev,
+                             size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

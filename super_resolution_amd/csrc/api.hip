@@ -417,36 +417,34 @@ size_t sr355_generator_workspace_bytes(const sr355_generator_cfg *cfg, int N, in
     return carve(*cfg, N, H, W).total;
 }
 
-int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
-                            const float *in_nchw, float *out_nchw, int N, int H, int W, void *workspace,
-                            size_t workspace_bytes, void *stream_) {
-    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
-    hipStream_t stream = (hipStream_t)stream_;
-    size_t total = 0;
-    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
-    if (N < 1 || H < 1 || W < 1 || !packed || !aligned16(packed) || packed_bytes < total || !in_nchw ||
-        !out_nchw) {
-        set_error("generator_forward: bad arguments (N=%d H=%d W=%d packed %zu of %zu bytes)", N, H, W,
-                  packed_bytes, total);
-        return SR355_ERR_INVALID;
-    }
-    const Workspace ws = carve(*cfg, N, H, W);
-    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < ws.total) {
-        set_error("generator_forward: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", ws.total,
-                  workspace_bytes);
-        return SR355_ERR_INVALID;
-    }
-    if ((size_t)16 * H * W * ws.nf_units * 16 >= ((size_t)1 << 31)) {
-        set_error("generator_forward: %dx%d input makes one HR feature map exceed 2 GiB; tile the image", H, W);
-        return SR355_ERR_UNSUPPORTED;
-    }
+// Buffers of one forward pass.  Inference ping-pongs two dense-block buffers; training keeps one per
+// dense block (plus the last one's x slice) because the backward pass needs every activation.
+struct FwdBufs {
+    unsigned char *x0;
+    unsigned char *blk_base;
+    size_t blk_stride;
+    int blk_count;       // 2 = ping-pong, otherwise 3*num_blocks + 1 distinct buffers
+    float *T, *R, *F;
+    unsigned char *L1, *H1, *H2, *H3;
+    unsigned char *blk(int i) const { return blk_base + (size_t)(blk_count == 2 ? (i & 1) : i) * blk_stride; }
+};
+
+static ConvArgs conv_args_zero() {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.res1_w = a.res2_w = 1.f;
+    a.slope = 1.f;
+    a.mask_slope = 1.f;
+    return a;
+}
+
+static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpec> &specs, const unsigned char *pk,
+                       const float *in_nchw, float *out_nchw, int N, int H, int W, const Workspace &ws,
+                       const FwdBufs &fb, hipStream_t stream) {
     const int dtype = cfg->dtype, cpu = unit_channels(dtype);
     const int nf = cfg->num_features, gc = cfg->growth_channels;
-    unsigned char *wsb = (unsigned char *)workspace;
-    const unsigned char *pk = (const unsigned char *)packed;
-    float *T = (float *)(wsb + ws.T), *R = (float *)(wsb + ws.R), *F = (float *)(wsb + ws.F);
-
-    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, wsb + ws.x0, ws.in_units,
+    float *T = fb.T, *R = fb.R, *F = fb.F;
+    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units,
                                     specs[0].split == SR355_SPLIT_INPUT, stream);
     if (rc) return rc;
 
@@ -455,8 +453,7 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
                     unsigned char *out_act, int out_units, int out_off, float slope, const float *res1, float s1,
                     const float *res2, float s2, float *out_f32, float *out_nc) -> int {
         const ConvSpec &sp = specs[ci++];
-        ConvArgs a;
-        memset(&a, 0, sizeof(a));
+        ConvArgs a = conv_args_zero();
         a.in = in;
         a.w = pk + sp.w_off;
         a.bias = (const float *)(pk + sp.b_off);
@@ -467,8 +464,6 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
         a.res2 = res2;
         a.res1_scale = s1;
         a.res2_scale = s2;
-        a.res1_w = 1.f;
-        a.res2_w = 1.f;
         a.slope = slope;
         a.N = N;
         a.H = h;
@@ -483,14 +478,15 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
         return launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, stream);
     };
 
-    unsigned char *cur = wsb + ws.bufA, *nxt = wsb + ws.bufB;
+    int bi = 0;  // dense-block buffer index
     // conv_first (:56): x -> block buffer units [0, nf) and the fp32 copy F kept for the global skip.
-    if ((rc = conv(wsb + ws.x0, ws.in_units, ws.in_units, H, W, 0, cur, ws.blk_units, 0, 1.f, nullptr, 0.f,
-                   nullptr, 0.f, F, nullptr)))
+    if ((rc = conv(fb.x0, ws.in_units, ws.in_units, H, W, 0, fb.blk(0), ws.blk_units, 0, 1.f, nullptr, 0.f, nullptr,
+                   0.f, F, nullptr)))
         return rc;
     for (int b = 0; b < cfg->num_blocks; ++b) {
         const float *rrdb_in = (b == 0) ? F : R;  // fp32 input of this RRDB (:35)
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 3; ++r, ++bi) {
+            unsigned char *cur = fb.blk(bi), *nxt = fb.blk(bi + 1);
             for (int k = 0; k < 4; ++k) {  // growth convs (:19-22): read [0, nf+k*gc), append gc channels
                 if ((rc = conv(cur, ws.blk_units, (nf + k * gc) / cpu, H, W, 0, cur, ws.blk_units,
                                (nf + k * gc) / cpu, 0.2f, nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
@@ -499,36 +495,479 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
             // conv5 + dense skip (:23-24); the third block also folds the RRDB skip (:39).
             const float *res1 = (r == 0) ? rrdb_in : T;
             if (r < 2)
-                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f,
-                          nullptr, 0.f, T, nullptr);
+                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f, nullptr,
+                          0.f, T, nullptr);
             else
-                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f,
-                          rrdb_in, 0.2f, R, nullptr);
+                rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f, rrdb_in,
+                          0.2f, R, nullptr);
             if (rc) return rc;
-            unsigned char *t = cur;
-            cur = nxt;
-            nxt = t;
         }
     }
     // trunk_conv + global skip (:57-58)
-    if ((rc = conv(cur, ws.blk_units, ws.nf_units, H, W, 0, wsb + ws.L1, ws.nf_units, 0, 1.f, F, 1.f, nullptr,
-                   0.f, nullptr, nullptr)))
+    if ((rc = conv(fb.blk(bi), ws.blk_units, ws.nf_units, H, W, 0, fb.L1, ws.nf_units, 0, 1.f, F, 1.f, nullptr, 0.f,
+                   nullptr, nullptr)))
         return rc;
     // nearest x2 + upconv1 + lrelu (:59), nearest x2 + upconv2 + lrelu (:60)
-    if ((rc = conv(wsb + ws.L1, ws.nf_units, ws.nf_units, 2 * H, 2 * W, 1, wsb + ws.H1, ws.nf_units, 0, 0.2f,
-                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+    if ((rc = conv(fb.L1, ws.nf_units, ws.nf_units, 2 * H, 2 * W, 1, fb.H1, ws.nf_units, 0, 0.2f, nullptr, 0.f,
+                   nullptr, 0.f, nullptr, nullptr)))
         return rc;
-    if ((rc = conv(wsb + ws.H1, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 1, wsb + ws.H2, ws.nf_units, 0, 0.2f,
-                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+    if ((rc = conv(fb.H1, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 1, fb.H2, ws.nf_units, 0, 0.2f, nullptr, 0.f,
+                   nullptr, 0.f, nullptr, nullptr)))
         return rc;
     // HR_conv + lrelu, conv_last (:61)
-    if ((rc = conv(wsb + ws.H2, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, wsb + ws.H3, ws.nf_units, 0, 0.2f,
-                   nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
+    if ((rc = conv(fb.H2, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, fb.H3, ws.nf_units, 0, 0.2f, nullptr, 0.f,
+                   nullptr, 0.f, nullptr, nullptr)))
         return rc;
-    if ((rc = conv(wsb + ws.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f,
-                   nullptr, 0.f, nullptr, out_nchw)))
-        return rc;
+    return conv(fb.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f, nullptr, 0.f,
+                nullptr, out_nchw);
+}
+
+static int forward_checks(const char *who, const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
+                          size_t packed_need, const float *in_nchw, float *out_nchw, int N, int H, int W) {
+    if (N < 1 || H < 1 || W < 1 || !packed || !aligned16(packed) || packed_bytes < packed_need || !in_nchw ||
+        !out_nchw) {
+        set_error("%s: bad arguments (N=%d H=%d W=%d packed %zu of %zu bytes)", who, N, H, W, packed_bytes,
+                  packed_need);
+        return SR355_ERR_INVALID;
+    }
+    if ((size_t)16 * H * W * (cfg->num_features / unit_channels(cfg->dtype)) * 16 >= ((size_t)1 << 31)) {
+        set_error("%s: %dx%d input makes one HR feature map exceed 2 GiB; tile the image", who, H, W);
+        return SR355_ERR_UNSUPPORTED;
+    }
     return SR355_OK;
+}
+
+int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
+                            const float *in_nchw, float *out_nchw, int N, int H, int W, void *workspace,
+                            size_t workspace_bytes, void *stream_) {
+    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
+    size_t total = 0;
+    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
+    int rc = forward_checks("generator_forward", cfg, packed, packed_bytes, total, in_nchw, out_nchw, N, H, W);
+    if (rc) return rc;
+    const Workspace ws = carve(*cfg, N, H, W);
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < ws.total) {
+        set_error("generator_forward: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", ws.total,
+                  workspace_bytes);
+        return SR355_ERR_INVALID;
+    }
+    unsigned char *wsb = (unsigned char *)workspace;
+    FwdBufs fb;
+    fb.x0 = wsb + ws.x0;
+    fb.blk_base = wsb + ws.bufA;
+    fb.blk_stride = ws.bufB - ws.bufA;
+    fb.blk_count = 2;
+    fb.T = (float *)(wsb + ws.T), fb.R = (float *)(wsb + ws.R), fb.F = (float *)(wsb + ws.F);
+    fb.L1 = wsb + ws.L1, fb.H1 = wsb + ws.H1, fb.H2 = wsb + ws.H2, fb.H3 = wsb + ws.H3;
+    return run_forward(cfg, specs, (const unsigned char *)packed, in_nchw, out_nchw, N, H, W, ws, fb,
+                       (hipStream_t)stream_);
+}
+
+// ---- training: forward that keeps activations, backward -------------------------------------
+// Saved activations (bf16 path only): blocked input, one dense-block buffer per dense block plus the
+// body output, the LR feature map fed to upconv1 and the three HR activations.
+struct Saved {
+    size_t x0, blk, L1, H1, H2, H3, total;
+    size_t blk_stride;
+    int n_blk;
+};
+
+static Saved carve_saved(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
+    Saved s;
+    const size_t P = (size_t)N * H * W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    s.n_blk = 3 * c.num_blocks + 1;
+    s.blk_stride = align256(P * ws.blk_units * 16);
+    s.x0 = take(P * ws.in_units * 16);
+    s.blk = take(s.blk_stride * s.n_blk);
+    s.L1 = take(P * ws.nf_units * 16);
+    s.H1 = take(4 * P * ws.nf_units * 16);
+    s.H2 = take(16 * P * ws.nf_units * 16);
+    s.H3 = take(16 * P * ws.nf_units * 16);
+    s.total = off;
+    return s;
+}
+
+static bool train_ok(const sr355_generator_cfg *cfg) {
+    if (!cfg_ok(cfg)) return false;
+    if (cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features > 64 || cfg->growth_channels > 64) {
+        set_error("training path: bf16 kernels with num_features, growth_channels <= 64 only");
+        return false;
+    }
+    return true;
+}
+
+size_t sr355_generator_saved_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    if (!train_ok(cfg) || N < 1 || H < 1 || W < 1) return 0;
+    return carve_saved(*cfg, carve(*cfg, N, H, W), N, H, W).total;
+}
+
+size_t sr355_generator_train_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    if (!train_ok(cfg) || N < 1 || H < 1 || W < 1) return 0;
+    return 3 * align256((size_t)N * H * W * cfg->num_features * 4);   // fp32 trunks T, R, F
+}
+
+int sr355_generator_forward_train(const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
+                                  const float *in_nchw, float *out_nchw, int N, int H, int W, void *saved,
+                                  size_t saved_bytes, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    size_t total = 0;
+    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
+    int rc = forward_checks("generator_forward_train", cfg, packed, packed_bytes, total, in_nchw, out_nchw, N, H, W);
+    if (rc) return rc;
+    const Workspace ws = carve(*cfg, N, H, W);
+    const Saved sv = carve_saved(*cfg, ws, N, H, W);
+    const size_t trunk = align256((size_t)N * H * W * cfg->num_features * 4);
+    if (!saved || (reinterpret_cast<uintptr_t>(saved) & 255) || saved_bytes < sv.total || !workspace ||
+        (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < 3 * trunk) {
+        set_error("generator_forward_train: need 256-byte aligned saved >= %zu and workspace >= %zu bytes", sv.total,
+                  3 * trunk);
+        return SR355_ERR_INVALID;
+    }
+    unsigned char *sb = (unsigned char *)saved, *wsb = (unsigned char *)workspace;
+    FwdBufs fb;
+    fb.x0 = sb + sv.x0;
+    fb.blk_base = sb + sv.blk;
+    fb.blk_stride = sv.blk_stride;
+    fb.blk_count = sv.n_blk;
+    fb.T = (float *)wsb, fb.R = (float *)(wsb + trunk), fb.F = (float *)(wsb + 2 * trunk);
+    fb.L1 = sb + sv.L1, fb.H1 = sb + sv.H1, fb.H2 = sb + sv.H2, fb.H3 = sb + sv.H3;
+    return run_forward(cfg, specs, (const unsigned char *)packed, in_nchw, out_nchw, N, H, W, ws, fb,
+                       (hipStream_t)stream_);
+}
+
+// Transposed (data-gradient) weights.  Per dense block five tensors, step j = 4..1 producing the gradient
+// of growth output x_j and step 0 the gradient of the block input x; then trunk_conv, upconv1, upconv2,
+// HR_conv, conv_last and conv_first.  Offsets into the blob; every tensor is followed by nothing (the
+// data-gradient convs use one shared all-zero bias at the start of the blob).
+struct BwdPack {
+    std::vector<size_t> rdb;   // [3*nb][5]: index (i*5 + j)
+    size_t trunk, up1, up2, hr, last, first, zero_bias, total;
+};
+
+static BwdPack carve_bwd(const sr355_generator_cfg &c) {
+    BwdPack p;
+    const int nf = c.num_features, gc = c.growth_channels;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    p.zero_bias = take(64 * sizeof(float));
+    p.rdb.resize((size_t)3 * c.num_blocks * 5);
+    for (int i = 0; i < 3 * c.num_blocks; ++i)
+        for (int j = 4; j >= 0; --j) {
+            const int cin = nf + (4 - j) * gc, cout = j ? gc : nf;
+            p.rdb[(size_t)i * 5 + j] = take((size_t)(cin / 8) * 9 * cout_pad_for(cout) * 16);
+        }
+    const size_t sq = (size_t)(nf / 8) * 9 * cout_pad_for(nf) * 16;
+    p.trunk = take(sq), p.up1 = take(sq), p.up2 = take(sq), p.hr = take(sq);
+    p.last = take((size_t)cin_units_for(c.out_channels, c.dtype) * 9 * cout_pad_for(nf) * 16);
+    p.first = take((size_t)(nf / 8) * 9 * cout_pad_for(c.in_channels) * 16);
+    p.total = off;
+    return p;
+}
+
+size_t sr355_generator_packed_bwd_bytes(const sr355_generator_cfg *cfg) {
+    if (!train_ok(cfg)) return 0;
+    return carve_bwd(*cfg).total;
+}
+
+int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const *w_ptrs, int n_convs, void *packed,
+                             size_t packed_bytes, void *stream_) {
+    if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    const BwdPack bp = carve_bwd(*cfg);
+    const int nb = cfg->num_blocks, nf = cfg->num_features, gc = cfg->growth_channels, dt = cfg->dtype;
+    if (!w_ptrs || n_convs != 1 + 15 * nb + 5 || !packed || !aligned16(packed) || packed_bytes < bp.total) {
+        set_error("generator_pack_bwd: need %d weight tensors and %zu bytes (got %d, %zu)", 1 + 15 * nb + 5, bp.total,
+                  n_convs, packed_bytes);
+        return SR355_ERR_INVALID;
+    }
+    for (int i = 0; i < n_convs; ++i)
+        if (!w_ptrs[i]) {
+            set_error("generator_pack_bwd: tensor %d is null", i);
+            return SR355_ERR_INVALID;
+        }
+    unsigned char *base = (unsigned char *)packed;
+    // zero the whole blob once: padded input units (conv_last) and the shared bias must read as zero
+    if (check_hip(hipMemsetAsync(base, 0, bp.total, stream), "hipMemsetAsync")) return SR355_ERR_HIP;
+    int rc;
+    for (int i = 0; i < 3 * nb; ++i) {
+        const float *const *w = w_ptrs + 1 + (size_t)i * 5;   // conv1..conv5 of dense block i
+        const float s5 = (i % 3 == 2) ? 0.04f : 0.2f;          // 0.2 (dense skip) x 0.2 (RRDB skip on the third block)
+        for (int j = 4; j >= 0; --j) {
+            const int ci_lo = j ? nf + (j - 1) * gc : 0, n_out = j ? gc : nf;
+            const int units = (nf + (4 - j) * gc) / 8, cp = cout_pad_for(n_out);
+            unsigned char *dst = base + bp.rdb[(size_t)i * 5 + j];
+            // gradient stack order: [dOut (nf) | dY4 | dY3 | dY2 | dY1]
+            if ((rc = launch_pack_weight_t(w[4], nf, nf + 4 * gc, ci_lo, n_out, dt, s5, dst, 0, cp, stream))) return rc;
+            for (int k = 4; k > j; --k) {   // conv_k (1-based) reads x_j when k > j
+                if ((rc = launch_pack_weight_t(w[k - 1], gc, nf + (k - 1) * gc, ci_lo, n_out, dt, 1.f, dst,
+                                               (nf + (4 - k) * gc) / 8, cp, stream)))
+                    return rc;
+            }
+            (void)units;
+        }
+    }
+    const float *const *tail = w_ptrs + 1 + (size_t)15 * nb;   // trunk_conv, upconv1, upconv2, HR_conv, conv_last
+    const size_t sq_off[4] = {bp.trunk, bp.up1, bp.up2, bp.hr};
+    for (int t = 0; t < 4; ++t)
+        if ((rc = launch_pack_weight_t(tail[t], nf, nf, 0, nf, dt, 1.f, base + sq_off[t], 0, cout_pad_for(nf), stream)))
+            return rc;
+    if ((rc = launch_pack_weight_t(tail[4], cfg->out_channels, nf, 0, nf, dt, 1.f, base + bp.last, 0, cout_pad_for(nf),
+                                   stream)))
+        return rc;
+    return launch_pack_weight_t(w_ptrs[0], nf, cfg->in_channels, 0, cfg->in_channels, dt, 1.f, base + bp.first, 0,
+                                cout_pad_for(cfg->in_channels), stream);
+}
+
+// Backward workspace.
+struct BwdWs {
+    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, dfea, slabs, total;
+};
+
+static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
+    BwdWs b;
+    const size_t P = (size_t)N * H * W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const int ou = cin_units_for(c.out_channels, c.dtype);
+    b.dout = take(16 * P * ou * 16);
+    b.G3 = take(16 * P * ws.nf_units * 16);
+    b.G2 = take(16 * P * ws.nf_units * 16);
+    b.G1u = take(16 * P * ws.nf_units * 16);
+    b.G1 = take(4 * P * ws.nf_units * 16);
+    b.G0u = take(4 * P * ws.nf_units * 16);
+    b.gL1 = take(P * c.num_features * 4);
+    b.gL1b = take(P * ws.nf_units * 16);
+    b.gT = take(P * c.num_features * 4);
+    b.gR = take(P * c.num_features * 4);
+    b.GB0 = take(P * ws.blk_units * 16);
+    b.GB1 = take(P * ws.blk_units * 16);
+    b.dfea = take(P * ws.nf_units * 16);
+    size_t slab = 0;
+    const int nf = c.num_features, gc = c.growth_channels;
+    auto upd = [&](int cout, int cin, int n, int h, int w) {
+        size_t s = wgrad_workspace_bytes(cout, cin, n, h, w);
+        if (s > slab) slab = s;
+    };
+    for (int k = 0; k < 4; ++k) upd(gc, nf + k * gc, N, H, W);
+    upd(nf, nf + 4 * gc, N, H, W);
+    upd(nf, c.in_channels, N, H, W);
+    upd(nf, nf, N, 2 * H, 2 * W);
+    upd(nf, nf, N, 4 * H, 4 * W);
+    upd(c.out_channels, nf, N, 4 * H, 4 * W);
+    b.slabs = take(slab);
+    b.total = off;
+    return b;
+}
+
+size_t sr355_generator_bwd_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    if (!train_ok(cfg) || N < 1 || H < 1 || W < 1 || cfg->out_channels > 64) return 0;
+    return carve_bwd_ws(*cfg, carve(*cfg, N, H, W), N, H, W).total;
+}
+
+size_t sr355_generator_grads_floats(const sr355_generator_cfg *cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    size_t n = 0;
+    for (const ConvSpec &s : conv_specs(*cfg, nullptr)) n += (size_t)s.cout * s.cin * 9 + s.cout;
+    return n;
+}
+
+// trunk sum -> blocked bf16 (the gradient reaching conv_first is the body path plus the global skip)
+__global__ void add_trunks_to_act_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                         __bf16 *__restrict__ out, size_t n_units8, int W, int f32_units) {
+    // one thread per (row, unit8, x): reads the two fp32 quads of that unit
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_units8; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t t = i / W;
+        const int u8 = (int)(t % (f32_units / 2));
+        const size_t row = t / (f32_units / 2);
+        __bf16 v[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t idx = (row * f32_units + 2 * u8 + q) * W + x;
+            const float4 va = a[idx], vb = b[idx];
+            v[4 * q + 0] = (__bf16)(va.x + vb.x);
+            v[4 * q + 1] = (__bf16)(va.y + vb.y);
+            v[4 * q + 2] = (__bf16)(va.z + vb.z);
+            v[4 * q + 3] = (__bf16)(va.w + vb.w);
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(out)[i] = pk;
+    }
+}
+
+int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_bwd, size_t packed_bwd_bytes,
+                             const void *saved, size_t saved_bytes, const float *grad_out_nchw, float *grads,
+                             size_t grads_floats, float *grad_in_nchw, int N, int H, int W, void *workspace,
+                             size_t workspace_bytes, void *stream_) {
+    if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    hipStream_t stream = (hipStream_t)stream_;
+    const std::vector<ConvSpec> specs = conv_specs(*cfg, nullptr);
+    const BwdPack bp = carve_bwd(*cfg);
+    const Workspace ws = carve(*cfg, N, H, W);
+    const Saved sv = carve_saved(*cfg, ws, N, H, W);
+    if (N < 1 || H < 1 || W < 1 || cfg->out_channels > 64) {
+        set_error("generator_backward: bad shape");
+        return SR355_ERR_INVALID;
+    }
+    const BwdWs bw = carve_bwd_ws(*cfg, ws, N, H, W);
+    const size_t need_grads = sr355_generator_grads_floats(cfg);
+    if (!packed_bwd || !aligned16(packed_bwd) || packed_bwd_bytes < bp.total || !saved ||
+        (reinterpret_cast<uintptr_t>(saved) & 255) || saved_bytes < sv.total || !grad_out_nchw || !grads ||
+        grads_floats < need_grads || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) ||
+        workspace_bytes < bw.total) {
+        set_error("generator_backward: buffers missing / misaligned / too small (packed %zu/%zu, saved %zu/%zu, grads "
+                  "%zu/%zu floats, workspace %zu/%zu)",
+                  packed_bwd_bytes, bp.total, saved_bytes, sv.total, grads_floats, need_grads, workspace_bytes,
+                  bw.total);
+        return SR355_ERR_INVALID;
+    }
+    const int nb = cfg->num_blocks, nf = cfg->num_features, gc = cfg->growth_channels, dt = cfg->dtype;
+    const int nfu = ws.nf_units, bu = ws.blk_units;
+    const unsigned char *pk = (const unsigned char *)packed_bwd;
+    const unsigned char *sb = (const unsigned char *)saved;
+    unsigned char *wb = (unsigned char *)workspace;
+    const float *zero_bias = (const float *)(pk + bp.zero_bias);
+    float *slabs = (float *)(wb + bw.slabs);
+    float *gL1 = (float *)(wb + bw.gL1), *gT = (float *)(wb + bw.gT), *gR = (float *)(wb + bw.gR);
+
+    // parameter-gradient offsets (state_dict order: weight, bias per conv)
+    std::vector<size_t> goff(specs.size());
+    {
+        size_t o = 0;
+        for (size_t i = 0; i < specs.size(); ++i) {
+            goff[i] = o;
+            o += (size_t)specs[i].cout * specs[i].cin * 9 + specs[i].cout;
+        }
+    }
+    auto wgrad = [&](size_t conv_idx, const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_off,
+                     int h, int w, float scale) -> int {
+        const ConvSpec &sp = specs[conv_idx];
+        float *dw = grads + goff[conv_idx];
+        return launch_wgrad3x3(in, in_units, ups, dy, dy_units, dy_off, N, h, w, sp.cout, sp.cin, scale, 0, dw,
+                               dw + (size_t)sp.cout * sp.cin * 9, slabs, stream);
+    };
+    // data-gradient conv: forward kernel on transposed weights, zero bias
+    auto dgrad = [&](const void *in, int in_units, int cin_units, size_t w_off, int cout, int h, int w,
+                     const void *mask, int mask_units, int mask_off, const float *res1, float r1w, const float *res2,
+                     float r2w, float *out_f32, void *out_act, int out_units, int out_off, float *out_nc) -> int {
+        ConvArgs a = conv_args_zero();
+        a.in = (const unsigned char *)in;
+        a.w = pk + w_off;
+        a.bias = zero_bias;
+        a.out_act = (unsigned char *)out_act;
+        a.out_f32 = out_f32;
+        a.out_nchw = out_nc;
+        a.res1 = res1, a.res1_w = r1w, a.res1_scale = 1.f;
+        a.res2 = res2, a.res2_w = r2w, a.res2_scale = 1.f;
+        a.mask_act = (const unsigned char *)mask;
+        a.mask_units = mask_units, a.mask_unit_off = mask_off, a.mask_slope = 0.2f;
+        a.N = N, a.H = h, a.W = w;
+        a.in_units = in_units;
+        a.out_units = out_units, a.out_unit_off = out_off;
+        a.cout_real = cout, a.cout_pad = cout_pad_for(cout);
+        a.f32_units = cout / 4;
+        return launch_conv3x3(a, dt, cin_units, 0, stream);
+    };
+    const size_t i_trunk = 1 + (size_t)15 * nb, i_up1 = i_trunk + 1, i_up2 = i_trunk + 2, i_hr = i_trunk + 3,
+                 i_last = i_trunk + 4;
+    const int ou = cin_units_for(cfg->out_channels, dt);
+    int rc;
+    // grad_out -> blocked bf16
+    if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
+        return rc;
+    // conv_last (:61)
+    if ((rc = wgrad(i_last, sb + sv.H3, nfu, 0, wb + bw.dout, ou, 0, 4 * H, 4 * W, 1.f))) return rc;
+    if ((rc = dgrad(wb + bw.dout, ou, ou, bp.last, nf, 4 * H, 4 * W, sb + sv.H3, nfu, 0, nullptr, 1.f, nullptr, 1.f,
+                    nullptr, wb + bw.G3, nfu, 0, nullptr)))
+        return rc;
+    // HR_conv
+    if ((rc = wgrad(i_hr, sb + sv.H2, nfu, 0, wb + bw.G3, nfu, 0, 4 * H, 4 * W, 1.f))) return rc;
+    if ((rc = dgrad(wb + bw.G3, nfu, nfu, bp.hr, nf, 4 * H, 4 * W, sb + sv.H2, nfu, 0, nullptr, 1.f, nullptr, 1.f,
+                    nullptr, wb + bw.G2, nfu, 0, nullptr)))
+        return rc;
+    // upconv2 (:60): input was nearest-x2(H1)
+    if ((rc = wgrad(i_up2, sb + sv.H1, nfu, 1, wb + bw.G2, nfu, 0, 4 * H, 4 * W, 1.f))) return rc;
+    if ((rc = dgrad(wb + bw.G2, nfu, nfu, bp.up2, nf, 4 * H, 4 * W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, nullptr,
+                    wb + bw.G1u, nfu, 0, nullptr)))
+        return rc;
+    if ((rc = launch_pool2x2(wb + bw.G1u, N, 2 * H, 2 * W, nfu, dt, sb + sv.H1, nfu, 0, 0.2f, nullptr, wb + bw.G1, nfu, 0,
+                             stream)))
+        return rc;
+    // upconv1 (:59): input was nearest-x2(L1); L1 = fea + trunk has no activation
+    if ((rc = wgrad(i_up1, sb + sv.L1, nfu, 1, wb + bw.G1, nfu, 0, 2 * H, 2 * W, 1.f))) return rc;
+    if ((rc = dgrad(wb + bw.G1, nfu, nfu, bp.up1, nf, 2 * H, 2 * W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, nullptr,
+                    wb + bw.G0u, nfu, 0, nullptr)))
+        return rc;
+    if ((rc = launch_pool2x2(wb + bw.G0u, N, H, W, nfu, dt, nullptr, 0, 0, 1.f, gL1, wb + bw.gL1b, nfu, 0, stream)))
+        return rc;
+    // trunk_conv (:57): its input is the body output = x slice of the last dense-block buffer
+    const unsigned char *body_out = sb + sv.blk + (size_t)(3 * nb) * sv.blk_stride;
+    unsigned char *GB[2] = {wb + bw.GB0, wb + bw.GB1};
+    int cur = 0;
+    if ((rc = wgrad(i_trunk, body_out, bu, 0, wb + bw.gL1b, nfu, 0, H, W, 1.f))) return rc;
+    if ((rc = dgrad(wb + bw.gL1b, nfu, nfu, bp.trunk, nf, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, gR, GB[cur],
+                    bu, 0, nullptr)))
+        return rc;
+    // RRDBs in reverse (:35-39, :18-24)
+    for (int b = nb - 1; b >= 0; --b) {
+        for (int r = 2; r >= 0; --r) {
+            const int i = 3 * b + r;
+            const unsigned char *A = sb + sv.blk + (size_t)i * sv.blk_stride;   // forward activations of this block
+            const size_t c1 = 1 + (size_t)i * 5;                                 // conv1 of this block in `specs`
+            const float s5 = (r == 2) ? 0.04f : 0.2f;
+            // conv5: dY5 = s5 * (gradient held in GB[cur] units [0, nf))
+            if ((rc = wgrad(c1 + 4, A, bu, 0, GB[cur], bu, 0, H, W, s5))) return rc;
+            for (int j = 4; j >= 1; --j) {
+                const int in_units = (nf + (4 - j) * gc) / 8, out_off = in_units;
+                if ((rc = dgrad(GB[cur], bu, in_units, bp.rdb[(size_t)i * 5 + j], gc, H, W, A, bu,
+                                (nf + (j - 1) * gc) / 8, nullptr, 1.f, nullptr, 1.f, nullptr, GB[cur], bu, out_off,
+                                nullptr)))
+                    return rc;
+                if ((rc = wgrad(c1 + (j - 1), A, bu, 0, GB[cur], bu, out_off, H, W, 1.f))) return rc;
+            }
+            const int nxt = cur ^ 1;
+            if (r == 2)        // dX3 = 0.2 gR + conv
+                rc = dgrad(GB[cur], bu, bu, bp.rdb[(size_t)i * 5], nf, H, W, nullptr, 0, 0, gR, 0.2f, nullptr, 1.f, gT,
+                           GB[nxt], bu, 0, nullptr);
+            else if (r == 1)   // dX2 = dX3 + conv
+                rc = dgrad(GB[cur], bu, bu, bp.rdb[(size_t)i * 5], nf, H, W, nullptr, 0, 0, gT, 1.f, nullptr, 1.f, gT,
+                           GB[nxt], bu, 0, nullptr);
+            else               // gradient of the RRDB input = gR + dX2 + conv
+                rc = dgrad(GB[cur], bu, bu, bp.rdb[(size_t)i * 5], nf, H, W, nullptr, 0, 0, gT, 1.f, gR, 1.f, gR,
+                           GB[nxt], bu, 0, nullptr);
+            if (rc) return rc;
+            cur = nxt;
+        }
+    }
+    // conv_first (:56): gradient of fea = body path (gR) + global skip (gL1)
+    {
+        const size_t n_units8 = (size_t)N * H * W * nfu;
+        size_t blocks = (n_units8 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(add_trunks_to_act_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float4 *)gR,
+                           (const float4 *)gL1, (__bf16 *)(wb + bw.dfea), n_units8, W, nf / 4);
+        if (check_hip(hipGetLastError(), "add_trunks launch")) return SR355_ERR_HIP;
+    }
+    if ((rc = wgrad(0, sb + sv.x0, ws.in_units, 0, wb + bw.dfea, nfu, 0, H, W, 1.f))) return rc;
+    if (grad_in_nchw)
+        rc = dgrad(wb + bw.dfea, nfu, nfu, bp.first, cfg->in_channels, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f,
+                   nullptr, nullptr, 0, 0, grad_in_nchw);
+    return rc;
 }
 
 }  // extern "C"

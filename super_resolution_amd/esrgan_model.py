@@ -153,6 +153,7 @@ class GeneratorRRDB(nn.Module):
             setattr(self, name, _conv(num_features, num_features))
         self.conv_last = _conv(num_features, out_channels)
         self._cache = _PackCache()
+        self._cache_bwd = _PackCache()
         self._workspace: Optional[Tensor] = None
 
     # -- parameter plumbing ---------------------------------------------------------------
@@ -186,13 +187,58 @@ class GeneratorRRDB(nn.Module):
             self._workspace = ws
         return ws
 
+    def packed_bwd_parameters(self) -> Tensor:
+        convs = self.conv_modules()
+        cfg = self.cfg()
+        return self._cache_bwd.get([c.weight for c in convs], (cfg[5], cfg[6]),
+                                   lambda: ops.generator_pack_bwd([c.weight.detach() for c in convs], cfg))
+
     # -- forward --------------------------------------------------------------------------
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
-        _no_grad_only(self, x)
-        xin = x.detach().float().contiguous()
+        xin = x.float().contiguous()
+        params = [p for c in self.conv_modules() for p in (c.weight, c.bias)]
+        if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
+            if _PRECISIONS[self.precision] != DTYPE_BF16:
+                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+            return _GeneratorFunction.apply(xin, self, *params)
         N, _c, H, W = xin.shape
-        return ops.generator_forward(xin, self.packed_parameters(), self.workspace(N, H, W, xin.device), self.cfg())
+        return ops.generator_forward(xin.detach(), self.packed_parameters(), self.workspace(N, H, W, xin.device),
+                                     self.cfg())
+
+
+class _GeneratorFunction(torch.autograd.Function):
+    """Autograd node of the whole generator: the forward keeps the activations in one buffer, the
+    backward is one ``sr355::generator_backward`` call that fills every parameter gradient
+    (what ``loss.backward()`` does over the recorded graph in esrgan/train.py:161, :220)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, module: "GeneratorRRDB", *params: Tensor) -> Tensor:
+        cfg = module.cfg()
+        N, _c, H, W = (int(v) for v in x.shape)
+        saved = torch.empty(ops.generator_saved_bytes(cfg, N, H, W), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(ops.generator_train_workspace_bytes(cfg, N, H, W), dtype=torch.uint8, device=x.device)
+        out = ops.generator_forward_train(x.detach(), module.packed_parameters(), saved, ws, cfg)
+        ctx.module, ctx.saved, ctx.lr_shape = module, saved, (N, H, W)
+        ctx.need_x = x.requires_grad
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        module, cfg = ctx.module, ctx.module.cfg()
+        N, H, W = ctx.lr_shape
+        ws = torch.empty(ops.generator_bwd_workspace_bytes(cfg, N, H, W), dtype=torch.uint8, device=grad_out.device)
+        flat, gin = ops.generator_backward(grad_out.float().contiguous(), module.packed_bwd_parameters(), ctx.saved, ws,
+                                           cfg, H, W, ctx.need_x)
+        grads, off = [], 0
+        for shape in ctx.param_shapes:
+            n = 1
+            for d in shape:
+                n *= d
+            grads.append(flat[off:off + n].view(shape))
+            off += n
+        return (gin if ctx.need_x else None, None, *grads)
 
 
 # RRDBNet is the name BasicSR-derived code uses for the same network.

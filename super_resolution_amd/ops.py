@@ -305,3 +305,106 @@ def generator_forward(x: Tensor, packed: Tensor, workspace: Tensor, cfg: List[in
 def _(x, packed, workspace, cfg):
     N, _c, H, W = x.shape
     return x.new_empty((N, cfg[1], 4 * H, 4 * W), dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------
+# training: forward that keeps activations + backward
+def _size(fn_name: str, cfg: List[int], *shape: int) -> int:
+    c = make_cfg(cfg)
+    n = getattr(_lib.lib(), fn_name)(C.byref(c), *shape)
+    if n == 0:
+        check(-1, fn_name)
+    return n
+
+
+def generator_saved_bytes(cfg: List[int], N: int, H: int, W: int) -> int:
+    return _size("sr355_generator_saved_bytes", cfg, N, H, W)
+
+
+def generator_train_workspace_bytes(cfg: List[int], N: int, H: int, W: int) -> int:
+    return _size("sr355_generator_train_workspace_bytes", cfg, N, H, W)
+
+
+def generator_bwd_workspace_bytes(cfg: List[int], N: int, H: int, W: int) -> int:
+    return _size("sr355_generator_bwd_workspace_bytes", cfg, N, H, W)
+
+
+def generator_grads_floats(cfg: List[int]) -> int:
+    return _size("sr355_generator_grads_floats", cfg)
+
+
+@torch.library.custom_op("sr355::generator_forward_train", mutates_args=("saved", "workspace"))
+def generator_forward_train(x: Tensor, packed: Tensor, saved: Tensor, workspace: Tensor, cfg: List[int]) -> Tensor:
+    """GeneratorRRDB.forward that also fills ``saved`` with the activations the backward pass reads."""
+    _need_cuda(x, packed, saved, workspace)
+    c = make_cfg(cfg)
+    N, _cin, H, W = (int(v) for v in x.shape)
+    out = torch.empty((N, c.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().sr355_generator_forward_train(C.byref(c), packed.data_ptr(), _nbytes(packed), x.data_ptr(),
+                                                       out.data_ptr(), N, H, W, saved.data_ptr(), _nbytes(saved),
+                                                       workspace.data_ptr(), _nbytes(workspace), _stream()),
+              "sr355_generator_forward_train")
+    return out
+
+
+@generator_forward_train.register_fake
+def _(x, packed, saved, workspace, cfg):
+    N, _c, H, W = x.shape
+    return x.new_empty((N, cfg[1], 4 * H, 4 * W), dtype=torch.float32)
+
+
+@torch.library.custom_op("sr355::generator_pack_bwd", mutates_args=())
+def generator_pack_bwd(weights: List[Tensor], cfg: List[int]) -> Tensor:
+    """Transposed (data-gradient) packing of every conv weight (state_dict order)."""
+    _need_cuda(*weights)
+    c = make_cfg(cfg)
+    L = _lib.lib()
+    nbytes = L.sr355_generator_packed_bwd_bytes(C.byref(c))
+    if nbytes == 0:
+        check(-1, "sr355_generator_packed_bwd_bytes")
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=weights[0].device)
+    n = len(weights)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
+    with torch.cuda.device(blob.device):
+        check(L.sr355_generator_pack_bwd(C.byref(c), wp, n, blob.data_ptr(), nbytes, _stream()),
+              "sr355_generator_pack_bwd")
+    return blob
+
+
+@generator_pack_bwd.register_fake
+def _(weights, cfg):
+    c = make_cfg(cfg)
+    return weights[0].new_empty(_lib.lib().sr355_generator_packed_bwd_bytes(C.byref(c)), dtype=torch.uint8)
+
+
+@torch.library.custom_op("sr355::generator_backward", mutates_args=("workspace",))
+def generator_backward(grad_out: Tensor, packed_bwd: Tensor, saved: Tensor, workspace: Tensor, cfg: List[int],
+                       lr_height: int, lr_width: int, need_input_grad: bool) -> Tuple[Tensor, Tensor]:
+    """Returns (flat fp32 parameter gradients: per conv weight then bias, gradient of the input or an
+    empty tensor)."""
+    _need_cuda(grad_out, packed_bwd, saved, workspace)
+    c = make_cfg(cfg)
+    N = int(grad_out.shape[0])
+    H, W = int(lr_height), int(lr_width)
+    L = _lib.lib()
+    nfl = L.sr355_generator_grads_floats(C.byref(c))
+    grads = torch.empty(nfl, dtype=torch.float32, device=grad_out.device)
+    gin = (torch.empty((N, c.in_channels, H, W), dtype=torch.float32, device=grad_out.device)
+           if need_input_grad else torch.empty(0, dtype=torch.float32, device=grad_out.device))
+    with torch.cuda.device(grad_out.device):
+        check(L.sr355_generator_backward(C.byref(c), packed_bwd.data_ptr(), _nbytes(packed_bwd), saved.data_ptr(),
+                                         _nbytes(saved), grad_out.data_ptr(), grads.data_ptr(), nfl,
+                                         gin.data_ptr() if need_input_grad else None, N, H, W,
+                                         workspace.data_ptr(), _nbytes(workspace), _stream()),
+              "sr355_generator_backward")
+    return grads, gin
+
+
+@generator_backward.register_fake
+def _(grad_out, packed_bwd, saved, workspace, cfg, lr_height, lr_width, need_input_grad):
+    c = make_cfg(cfg)
+    nfl = _lib.lib().sr355_generator_grads_floats(C.byref(c))
+    N = grad_out.shape[0]
+    gin = grad_out.new_empty((N, cfg[0], lr_height, lr_width) if need_input_grad else (0,))
+    return grad_out.new_empty(nfl), gin

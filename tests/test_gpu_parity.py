@@ -309,8 +309,8 @@ def test_generator_call_site_contract():
         net.conv_last.bias += 0.25
         d = net(x)
     assert (d - a - 0.25).abs().max().item() < 1e-5
-    with pytest.raises(NotImplementedError):
-        net(x)                                    # grad mode + trainable parameters: backward not wired
+    e = net(x)                                    # grad mode + trainable parameters: recorded for backward
+    assert e.requires_grad and torch.equal(e.detach(), d)
 
 
 def test_config2_size_properties():
