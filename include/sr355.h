@@ -49,7 +49,7 @@ extern "C" {
 #define SR355_SPLIT_WEIGHT 1
 #define SR355_SPLIT_INPUT 2
 
-#define SR355_ABI_VERSION 5
+#define SR355_ABI_VERSION 6
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -207,6 +207,19 @@ int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_
                              const float *grad_out_nchw_dev, float *grads_dev, size_t grads_floats,
                              float *grad_in_nchw_dev, int N, int H, int W, void *workspace_dev,
                              size_t workspace_bytes, void *stream);
+
+/* The backward pass in ordered phases, so that a data-parallel host can start the all-reduce of the
+ * gradients a phase has finished while later phases still compute (no counterpart in the reference,
+ * whose nn.DataParallel reduces after the whole backward: /root/reference/esrgan/train.py:108-111).
+ * Phase 0 = conv_last .. trunk_conv, phase p in [1, num_blocks] = RRDB (num_blocks - p),
+ * phase num_blocks + 1 = conv_first; a phase writes exactly the gradients of its own convs.
+ * Phases must run in increasing order with the same buffers. */
+int sr355_generator_backward_phases(const sr355_generator_cfg *cfg);
+int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *packed_bwd_dev,
+                                   size_t packed_bwd_bytes, const void *saved_dev, size_t saved_bytes,
+                                   const float *grad_out_nchw_dev, float *grads_dev, size_t grads_floats,
+                                   float *grad_in_nchw_dev, int N, int H, int W, void *workspace_dev,
+                                   size_t workspace_bytes, int phase_begin, int phase_end, void *stream);
 
 #ifdef __cplusplus
 }

@@ -186,12 +186,14 @@ def generator_forward_tiled(sd: StateDict, x: torch.Tensor, bands: int, halo: in
 # --------------------------------------------------------------------------
 # backward (autograd over the functional restatement)
 # --------------------------------------------------------------------------
-def generator_grads(sd: StateDict, x: torch.Tensor, grad_out: torch.Tensor,
-                    input_grad: bool = False) -> Tuple[torch.Tensor, StateDict, Optional[torch.Tensor]]:
-    """d(sum(out * grad_out)) / d(params[, x]) — what ``out.backward(grad_out)`` leaves in ``.grad``."""
+def generator_grads(sd: StateDict, x: torch.Tensor, grad_out: torch.Tensor, input_grad: bool = False,
+                    emulate_bf16=False) -> Tuple[torch.Tensor, StateDict, Optional[torch.Tensor]]:
+    """d(sum(out * grad_out)) / d(params[, x]) — what ``out.backward(grad_out)`` leaves in ``.grad``.
+    With ``emulate_bf16`` the forward rounds like the bf16 HIP path (the casts pass gradients through),
+    so the LeakyReLU sign pattern matches the one the HIP backward sees."""
     leaves = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in sd.items())
     xin = x.detach().clone().requires_grad_(input_grad)
-    out = generator_forward(leaves, xin)
+    out = generator_forward(leaves, xin, emulate_bf16)
     out.backward(grad_out)
     grads = OrderedDict((k, v.grad) for k, v in leaves.items())
     return out.detach(), grads, (xin.grad if input_grad else None)

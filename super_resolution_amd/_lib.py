@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 
 # every symbol include/sr355.h declares
@@ -30,6 +30,7 @@ EXPORTS = (
     "sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes", "sr355_generator_forward_train",
     "sr355_generator_packed_bwd_bytes", "sr355_generator_pack_bwd", "sr355_generator_bwd_workspace_bytes",
     "sr355_generator_grads_floats", "sr355_generator_backward",
+    "sr355_generator_backward_phases", "sr355_generator_backward_range",
 )
 
 
@@ -135,6 +136,8 @@ def lib() -> C.CDLL:
     L.sr355_generator_forward_train.argtypes = [cfgp, vp, sz, vp, vp, i, i, i, vp, sz, vp, sz, vp]
     L.sr355_generator_pack_bwd.argtypes = [cfgp, C.POINTER(vp), i, vp, sz, vp]
     L.sr355_generator_backward.argtypes = [cfgp, vp, sz, vp, sz, vp, vp, sz, vp, i, i, i, vp, sz, vp]
+    L.sr355_generator_backward_phases.argtypes = [cfgp]
+    L.sr355_generator_backward_range.argtypes = [cfgp, vp, sz, vp, sz, vp, vp, sz, vp, i, i, i, vp, sz, i, i, vp]
     if L.sr355_abi_version() != ABI_VERSION:
         raise Sr355Error(f"libsr355.so ABI {L.sr355_abi_version()} != expected {ABI_VERSION}; rebuild")
     _lib = L

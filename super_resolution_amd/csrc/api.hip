@@ -810,11 +810,23 @@ __global__ void add_trunks_to_act_kernel(const float4 *__restrict__ a, const flo
     }
 }
 
-int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_bwd, size_t packed_bwd_bytes,
-                             const void *saved, size_t saved_bytes, const float *grad_out_nchw, float *grads,
-                             size_t grads_floats, float *grad_in_nchw, int N, int H, int W, void *workspace,
-                             size_t workspace_bytes, void *stream_) {
+int sr355_generator_backward_phases(const sr355_generator_cfg *cfg) {
     if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    return cfg->num_blocks + 2;
+}
+
+// Phase p of the backward pass: 0 = conv_last .. trunk_conv, 1..num_blocks = RRDB (num_blocks - p),
+// num_blocks + 1 = conv_first.  Phases must run in order; state between them lives in `workspace`.
+int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *packed_bwd, size_t packed_bwd_bytes,
+                                   const void *saved, size_t saved_bytes, const float *grad_out_nchw, float *grads,
+                                   size_t grads_floats, float *grad_in_nchw, int N, int H, int W, void *workspace,
+                                   size_t workspace_bytes, int phase_begin, int phase_end, void *stream_) {
+    if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    if (phase_begin < 0 || phase_end > cfg->num_blocks + 2 || phase_begin >= phase_end) {
+        set_error("generator_backward: phase range [%d, %d) outside [0, %d)", phase_begin, phase_end,
+                  cfg->num_blocks + 2);
+        return SR355_ERR_INVALID;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const std::vector<ConvSpec> specs = conv_specs(*cfg, nullptr);
     const BwdPack bp = carve_bwd(*cfg);
@@ -886,7 +898,9 @@ int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_
     const size_t i_trunk = 1 + (size_t)15 * nb, i_up1 = i_trunk + 1, i_up2 = i_trunk + 2, i_hr = i_trunk + 3,
                  i_last = i_trunk + 4;
     const int ou = cin_units_for(cfg->out_channels, dt);
-    int rc;
+    int rc = SR355_OK;
+    unsigned char *GB[2] = {wb + bw.GB0, wb + bw.GB1};
+    if (phase_begin == 0) {
     // grad_out -> blocked bf16
     if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
         return rc;
@@ -917,14 +931,16 @@ int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_
         return rc;
     // trunk_conv (:57): its input is the body output = x slice of the last dense-block buffer
     const unsigned char *body_out = sb + sv.blk + (size_t)(3 * nb) * sv.blk_stride;
-    unsigned char *GB[2] = {wb + bw.GB0, wb + bw.GB1};
-    int cur = 0;
     if ((rc = wgrad(i_trunk, body_out, bu, 0, wb + bw.gL1b, nfu, 0, H, W, 1.f))) return rc;
-    if ((rc = dgrad(wb + bw.gL1b, nfu, nfu, bp.trunk, nf, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, gR, GB[cur],
+    if ((rc = dgrad(wb + bw.gL1b, nfu, nfu, bp.trunk, nf, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f, gR, GB[0],
                     bu, 0, nullptr)))
         return rc;
-    // RRDBs in reverse (:35-39, :18-24)
+    }   // phase 0
+    // RRDBs in reverse (:35-39, :18-24); the gradient-stack buffer alternates once per dense block
     for (int b = nb - 1; b >= 0; --b) {
+        const int phase = nb - b;
+        if (phase < phase_begin || phase >= phase_end) continue;
+        int cur = (3 * (nb - 1 - b)) & 1;
         for (int r = 2; r >= 0; --r) {
             const int i = 3 * b + r;
             const unsigned char *A = sb + sv.blk + (size_t)i * sv.blk_stride;   // forward activations of this block
@@ -954,6 +970,7 @@ int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_
             cur = nxt;
         }
     }
+    if (phase_end < nb + 2) return SR355_OK;
     // conv_first (:56): gradient of fea = body path (gR) + global skip (gL1)
     {
         const size_t n_units8 = (size_t)N * H * W * nfu;
@@ -968,6 +985,16 @@ int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_
         rc = dgrad(wb + bw.dfea, nfu, nfu, bp.first, cfg->in_channels, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f,
                    nullptr, nullptr, 0, 0, grad_in_nchw);
     return rc;
+}
+
+int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_bwd, size_t packed_bwd_bytes,
+                             const void *saved, size_t saved_bytes, const float *grad_out_nchw, float *grads,
+                             size_t grads_floats, float *grad_in_nchw, int N, int H, int W, void *workspace,
+                             size_t workspace_bytes, void *stream_) {
+    if (!train_ok(cfg)) return SR355_ERR_INVALID;
+    return sr355_generator_backward_range(cfg, packed_bwd, packed_bwd_bytes, saved, saved_bytes, grad_out_nchw, grads,
+                                          grads_floats, grad_in_nchw, N, H, W, workspace, workspace_bytes, 0,
+                                          cfg->num_blocks + 2, stream_);
 }
 
 }  // extern "C"

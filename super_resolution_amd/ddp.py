@@ -1,0 +1,127 @@
+"""Data-parallel training of the generator: one process per GPU, bucketed gradient all-reduce over
+RCCL overlapped with the backward pass.
+
+The reference trains under ``nn.DataParallel`` (/root/reference/esrgan/train.py:108-111): one process,
+parameters broadcast every forward, gradients reduced onto GPU 0 after the whole backward.  Here every
+rank keeps its own replica and its own batch; the backward pass runs in ordered phases
+(``sr355_generator_backward_range``) and as soon as a phase group has written its slice of the flat
+gradient buffer that slice is all-reduced asynchronously while the next group computes.  Gradients of
+the HR-side convs come first, then RRDB 22 .. 0, then conv_first: the buckets are contiguous slices
+taken from the END of the flat buffer towards its start.
+
+The mean over ranks equals the reference's mean over the gathered batch when ranks hold equal batches.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+
+def conv_grad_sizes(in_channels: int, out_channels: int, nf: int, nb: int, gc: int) -> List[int]:
+    """Floats of (weight + bias) gradient per conv in state_dict order."""
+    sizes = [nf * in_channels * 9 + nf]
+    for _ in range(3 * nb):
+        for k in range(5):
+            cin, cout = nf + k * gc, (gc if k < 4 else nf)
+            sizes.append(cout * cin * 9 + cout)
+    sizes += [nf * nf * 9 + nf] * 4
+    sizes.append(out_channels * nf * 9 + out_channels)
+    return sizes
+
+
+def phase_slices(in_channels: int, out_channels: int, nf: int, nb: int, gc: int) -> List[Tuple[int, int]]:
+    """[lo, hi) float range of the flat gradient buffer written by each backward phase."""
+    sizes = conv_grad_sizes(in_channels, out_channels, nf, nb, gc)
+    starts = [0]
+    for s in sizes:
+        starts.append(starts[-1] + s)
+    out = [(starts[1 + 15 * nb], starts[-1])]                         # phase 0: trunk_conv .. conv_last
+    for p in range(1, nb + 1):                                        # phase p: RRDB nb - p
+        b = nb - p
+        out.append((starts[1 + 15 * b], starts[1 + 15 * (b + 1)]))
+    out.append((0, starts[1]))                                        # last phase: conv_first
+    return out
+
+
+def plan_buckets(slices: Sequence[Tuple[int, int]], bucket_floats: int) -> List[Tuple[int, int, int, int]]:
+    """Group consecutive phases into buckets of at least ``bucket_floats`` floats:
+    (phase_begin, phase_end, lo, hi) with [lo, hi) contiguous in the flat buffer."""
+    buckets, begin = [], 0
+    while begin < len(slices):
+        end, lo, hi = begin, slices[begin][0], slices[begin][1]
+        while True:
+            end += 1
+            if end >= len(slices) or hi - lo >= bucket_floats:
+                break
+            lo = min(lo, slices[end][0])
+            hi = max(hi, slices[end][1])
+        buckets.append((begin, end, lo, hi))
+        begin = end
+    # phases walk the buffer backwards, so every bucket must be one contiguous range
+    for (_b, _e, lo, hi), (pb, pe) in zip(buckets, [(b[0], b[1]) for b in buckets]):
+        assert sum(s[1] - s[0] for s in slices[pb:pe]) == hi - lo
+    return buckets
+
+
+def reduce_in_buckets(flat: Tensor, buckets: Sequence[Tuple[int, int, int, int]],
+                      run_phases: Callable[[int, int], None], group=None) -> None:
+    """Run the phase groups in order; after each, start the all-reduce (mean) of its slice and go on."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    avg = dist.get_backend(group) == "nccl"
+    handles = []
+    for pb, pe, lo, hi in buckets:
+        run_phases(pb, pe)
+        view = flat[lo:hi]
+        if avg:
+            handles.append((dist.all_reduce(view, op=dist.ReduceOp.AVG, group=group, async_op=True), view, None))
+        elif view.is_cuda:
+            # gloo (tests, CPU-only fabrics): device tensors are staged through host memory
+            host = view.cpu()
+            handles.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group, async_op=True), view, host))
+        else:
+            handles.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group, async_op=True), view, None))
+    for h, view, host in handles:
+        h.wait()
+        if host is not None:
+            view.copy_(host)
+        if not avg:
+            view.div_(world)
+
+
+class DistributedGenerator(nn.Module):
+    """Wraps a ``GeneratorRRDB`` replica.  ``forward`` is the module's own; in grad mode the backward pass
+    all-reduces the gradients bucket by bucket while it runs.  Call ``broadcast_parameters()`` once after
+    construction so that every rank starts from rank 0's weights."""
+
+    def __init__(self, module: nn.Module, bucket_mb: float = 16.0, group=None):
+        super().__init__()
+        self.module = module
+        self.group = group
+        m = module
+        self.slices = phase_slices(m.in_channels, m.out_channels, m.num_features, m.num_blocks, m.growth_channels)
+        self.buckets = plan_buckets(self.slices, int(bucket_mb * (1 << 20) / 4))
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        import torch.distributed as dist
+        staged = dist.get_backend(self.group) != "nccl"
+        for p in self.module.parameters():
+            if staged and p.is_cuda:
+                host = p.data.cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                p.data.copy_(host)
+            else:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .esrgan_model import _GeneratorFunction
+        m = self.module
+        xin = x.float().contiguous()
+        params = [p for c in m.conv_modules() for p in (c.weight, c.bias)]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _GeneratorFunction.apply(xin, m, self, *params)
+        return m(x)

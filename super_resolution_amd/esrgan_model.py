@@ -201,7 +201,7 @@ class GeneratorRRDB(nn.Module):
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
             if _PRECISIONS[self.precision] != DTYPE_BF16:
                 raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
-            return _GeneratorFunction.apply(xin, self, *params)
+            return _GeneratorFunction.apply(xin, self, None, *params)
         N, _c, H, W = xin.shape
         return ops.generator_forward(xin.detach(), self.packed_parameters(), self.workspace(N, H, W, xin.device),
                                      self.cfg())
@@ -213,13 +213,13 @@ class _GeneratorFunction(torch.autograd.Function):
     (what ``loss.backward()`` does over the recorded graph in esrgan/train.py:161, :220)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, module: "GeneratorRRDB", *params: Tensor) -> Tensor:
+    def forward(ctx, x: Tensor, module: "GeneratorRRDB", reducer, *params: Tensor) -> Tensor:
         cfg = module.cfg()
         N, _c, H, W = (int(v) for v in x.shape)
         saved = torch.empty(ops.generator_saved_bytes(cfg, N, H, W), dtype=torch.uint8, device=x.device)
         ws = torch.empty(ops.generator_train_workspace_bytes(cfg, N, H, W), dtype=torch.uint8, device=x.device)
         out = ops.generator_forward_train(x.detach(), module.packed_parameters(), saved, ws, cfg)
-        ctx.module, ctx.saved, ctx.lr_shape = module, saved, (N, H, W)
+        ctx.module, ctx.saved, ctx.lr_shape, ctx.reducer = module, saved, (N, H, W), reducer
         ctx.need_x = x.requires_grad
         ctx.param_shapes = [tuple(p.shape) for p in params]
         return out
@@ -229,8 +229,19 @@ class _GeneratorFunction(torch.autograd.Function):
         module, cfg = ctx.module, ctx.module.cfg()
         N, H, W = ctx.lr_shape
         ws = torch.empty(ops.generator_bwd_workspace_bytes(cfg, N, H, W), dtype=torch.uint8, device=grad_out.device)
-        flat, gin = ops.generator_backward(grad_out.float().contiguous(), module.packed_bwd_parameters(), ctx.saved, ws,
-                                           cfg, H, W, ctx.need_x)
+        gout = grad_out.float().contiguous()
+        if ctx.reducer is None:
+            flat, gin = ops.generator_backward(gout, module.packed_bwd_parameters(), ctx.saved, ws, cfg, H, W, ctx.need_x)
+        else:
+            # data parallel: phase groups, each followed by the asynchronous all-reduce of its gradient slice
+            from .ddp import reduce_in_buckets
+            flat = torch.empty(ops.generator_grads_floats(cfg), dtype=torch.float32, device=gout.device)
+            gin = (torch.empty((N, module.in_channels, H, W), dtype=torch.float32, device=gout.device)
+                   if ctx.need_x else None)
+            packed_bwd = module.packed_bwd_parameters()
+            reduce_in_buckets(flat, ctx.reducer.buckets,
+                              lambda pb, pe: ops.generator_backward_range(gout, packed_bwd, ctx.saved, ws, flat, gin, cfg,
+                                                                          H, W, pb, pe), ctx.reducer.group)
         grads, off = [], 0
         for shape in ctx.param_shapes:
             n = 1
@@ -238,7 +249,7 @@ class _GeneratorFunction(torch.autograd.Function):
                 n *= d
             grads.append(flat[off:off + n].view(shape))
             off += n
-        return (gin if ctx.need_x else None, None, *grads)
+        return (gin if ctx.need_x else None, None, None, *grads)
 
 
 # RRDBNet is the name BasicSR-derived code uses for the same network.

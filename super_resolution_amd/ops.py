@@ -408,3 +408,24 @@ def _(grad_out, packed_bwd, saved, workspace, cfg, lr_height, lr_width, need_inp
     N = grad_out.shape[0]
     gin = grad_out.new_empty((N, cfg[0], lr_height, lr_width) if need_input_grad else (0,))
     return grad_out.new_empty(nfl), gin
+
+
+@torch.library.custom_op("sr355::generator_backward_range", mutates_args=("grads", "grad_in", "workspace"))
+def generator_backward_range(grad_out: Tensor, packed_bwd: Tensor, saved: Tensor, workspace: Tensor, grads: Tensor,
+                             grad_in: Optional[Tensor], cfg: List[int], lr_height: int, lr_width: int,
+                             phase_begin: int, phase_end: int) -> None:
+    """Phases [phase_begin, phase_end) of the backward pass (see sr355_generator_backward_range); each
+    phase writes the gradients of its own convs into the flat ``grads`` buffer."""
+    _need_cuda(grad_out, packed_bwd, saved, workspace, grads, grad_in)
+    c = make_cfg(cfg)
+    with torch.cuda.device(grad_out.device):
+        check(_lib.lib().sr355_generator_backward_range(
+            C.byref(c), packed_bwd.data_ptr(), _nbytes(packed_bwd), saved.data_ptr(), _nbytes(saved),
+            grad_out.data_ptr(), grads.data_ptr(), grads.numel(), _ptr(grad_in), int(grad_out.shape[0]),
+            int(lr_height), int(lr_width), workspace.data_ptr(), _nbytes(workspace), int(phase_begin), int(phase_end),
+            _stream()), "sr355_generator_backward_range")
+
+
+@generator_backward_range.register_fake
+def _(grad_out, packed_bwd, saved, workspace, grads, grad_in, cfg, lr_height, lr_width, phase_begin, phase_end):
+    return None

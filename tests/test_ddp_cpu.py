@@ -1,0 +1,83 @@
+"""CPU (gloo, world_size 2): bucket planning and the overlap orchestration of the data-parallel backward,
+with a stand-in for the HIP phase executor."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import esrgan_oracle as O
+from super_resolution_amd import ddp
+
+
+def test_phase_slices_tile_the_flat_gradient_buffer():
+    nb = 23
+    sl = ddp.phase_slices(3, 3, 64, nb, 32)
+    assert len(sl) == nb + 2
+    total = sum(v.numel() for v in O.make_generator_state(0).values())
+    assert total == 16697987
+    # phases walk the buffer from its end to its start without gaps or overlaps
+    assert sl[0][1] == total and sl[-1] == (0, 64 * 3 * 9 + 64)
+    for a, b in zip(sl, sl[1:]):
+        assert b[1] == a[0]
+    # a phase's slice is exactly its convs' (weight, bias) tensors in state_dict order
+    sizes = ddp.conv_grad_sizes(3, 3, 64, nb, 32)
+    names = [n for n, _ci, _co in O.generator_conv_specs()]
+    assert len(sizes) == len(names) == 351
+    assert sl[1][1] - sl[1][0] == sum(sizes[1 + 15 * 22: 1 + 15 * 23])
+
+
+def test_bucket_plan_is_contiguous_and_ordered():
+    sl = ddp.phase_slices(3, 3, 64, 23, 32)
+    buckets = ddp.plan_buckets(sl, int(16 * (1 << 20) / 4))
+    assert 3 <= len(buckets) <= 8
+    assert buckets[0][0] == 0 and buckets[-1][1] == len(sl)
+    covered = 0
+    for (pb, pe, lo, hi), nxt in zip(buckets, buckets[1:] + [None]):
+        assert pb < pe and lo < hi
+        covered += hi - lo
+        if nxt:
+            assert nxt[0] == pe and nxt[3] == lo
+    assert covered == 16697987
+    one = ddp.plan_buckets(sl, 1 << 40)
+    assert len(one) == 1 and one[0] == (0, len(sl), 0, 16697987)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nb = 3
+    sl = ddp.phase_slices(3, 3, 64, nb, 32)
+    buckets = ddp.plan_buckets(sl, 400_000)
+    n = sl[0][1]
+    flat = torch.full((n,), float("nan"))
+    order = []
+
+    def run_phases(pb, pe):          # stand-in for sr355::generator_backward_range: fills its own slices only
+        for p in range(pb, pe):
+            lo, hi = sl[p]
+            flat[lo:hi] = (rank + 1) * (p + 1)
+            order.append(p)
+
+    ddp.reduce_in_buckets(flat, buckets, run_phases)
+    expect = torch.empty(n)
+    for p, (lo, hi) in enumerate(sl):
+        expect[lo:hi] = (p + 1) * sum(r + 1 for r in range(world)) / world
+    if rank == 0:
+        ret["ok"] = bool(torch.equal(flat, expect))
+        ret["order"] = order == list(range(nb + 2))
+        ret["buckets"] = len(buckets)
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_gloo():
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["ok"] and ret["order"] and ret["buckets"] >= 2
