@@ -35,9 +35,11 @@ def conv_flops(cin, cout, pixels):
     return 2.0 * 9 * cin * cout * pixels
 
 
-def measure_kernels(net, N, H, W, reps=10):
+def measure_kernels(net, N, H, W, forwards=3):
     """Time every distinct conv launch configuration of one forward on cfg-sized buffers and
-    aggregate per kernel instantiation (Cout<=32 -> MB=1 symbol, Cout 64 -> MB=2 symbol)."""
+    aggregate per kernel instantiation (Cout<=32 -> MB=1 symbol, Cout 64 -> MB=2 symbol).  Each shape is
+    launched ``forwards`` x its per-forward count, so the launch mix of this pass equals that of the timed
+    forwards and a profiler's per-symbol average over the whole run is the same average."""
     import super_resolution_amd as S
     from super_resolution_amd import ops
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -51,13 +53,17 @@ def measure_kernels(net, N, H, W, reps=10):
     outer = trunk.clone()
     P = N * H * W
 
-    def timed(fn):
-        fn()
+    def timed(count, *conv):
+        """Average duration of one launch: the argument record is built once, then the C entry point is
+        called back to back on torch's current stream between two HIP events recorded on that stream."""
+        a = ops.conv_args(*conv)
+        reps = count * forwards
+        ops.launch_conv(a)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fn()
+            ops.launch_conv(a)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
@@ -66,13 +72,13 @@ def measure_kernels(net, N, H, W, reps=10):
     for k in range(4):
         wp, bp = packed[k]
         cu = (nf + k * gc) // 8
-        tk = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, gc, 0.2, 0, None, 0.0, None, 0.0, buf, cu, None, None))
+        tk = timed(3 * nb, buf, cu, wp, bp, gc, 0.2, 0, None, 0.0, None, 0.0, buf, cu, None, None)
         rows.append(("MB1", f"conv{k + 1} {nf + k * gc}->{gc}", 3 * nb, conv_flops(nf + k * gc, gc, P), tk))
     wp, bp = packed[4]
     cu = (nf + 4 * gc) // 8
-    t5 = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None))
+    t5 = timed(2 * nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None)
     rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5))
-    t5b = timed(lambda: ops.conv3x3_fwd(buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None))
+    t5b = timed(nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None)
     rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b))
     # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
     sp = 1 if net.hr_split else 0   # HR-side convs carry the weight rounding residue (2x MFMA work)
@@ -85,15 +91,15 @@ def measure_kernels(net, N, H, W, reps=10):
     h3 = torch.empty_like(h2)
     out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
     nu = nf // 8
-    ta = timed(lambda: ops.conv3x3_fwd(lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, sp))
+    ta = timed(1, lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, sp)
     rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta))
-    tb = timed(lambda: ops.conv3x3_fwd(h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, sp))
+    tb = timed(1, h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, sp)
     rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb))
-    tc = timed(lambda: ops.conv3x3_fwd(h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, sp))
+    tc = timed(1, h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, sp)
     rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc))
-    td = timed(lambda: ops.conv3x3_fwd(h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, sp))
+    td = timed(1, h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, sp)
     rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td))
-    tt = timed(lambda: ops.conv3x3_fwd(buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None))
+    tt = timed(1, buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None)
     rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt))
     return rows
 
@@ -115,7 +121,10 @@ def roofline_from(rows):
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
-            "flop_per_launch": d["flop_per_launch"]}
+            "flop_per_launch": d["flop_per_launch"],
+            "how": "whole-batch launches of every conv shape of one forward, in the forward's launch mix, back to back on "
+                   "one stream between two HIP events; the timed forwards themselves run two half-batches on two "
+                   "streams, where launches overlap and a per-launch duration is not a kernel rate"}
     other = {names[s]: {"achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / PEAK_BF16_TFLOPS, 4),
                         "avg_launch_us": round(v["avg_launch_us"], 2)} for s, v in out.items() if s != dom}
     per_shape = [{"kernel": sym, "shape": name, "us": round(sec * 1e6, 2), "tflops": round(fl / sec / 1e12, 1)}
@@ -143,15 +152,66 @@ def cpu_baseline(H, W):
                       f"{med:.3f} s each, torch CPU threads={cores}"}
 
 
+def train_rate(dev, world, dist, steps=5, warmup=2):
+    """Extra figure beside the headline: the generator's pixel-loss training step of the reference
+    (esrgan/train.py:156-163: forward, L1 loss, backward, Adam) on 16 LR patches of 32x32 per GPU, with
+    the bucketed gradient all-reduce when more than one rank runs.  Not the full adversarial step."""
+    import super_resolution_amd as S
+    from super_resolution_amd.ddp import DistributedGenerator
+    torch.manual_seed(0)
+    net = S.GeneratorRRDB(precision="bf16").to(dev).train()
+    model = DistributedGenerator(net) if world > 1 else net
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    lr = torch.rand(16, 3, 32, 32, device=dev)
+    hr = torch.rand(16, 3, 128, 128, device=dev)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(model(lr), hr)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    assert bool(torch.isfinite(loss))
+    flop = 3 * FLOP_PER_LR_PIXEL * 16 * 32 * 32          # backward = 2 forward-equivalents
+    return {"metric": "generator pixel-loss training step, patches/s", "value": round(world * 16 * steps / el, 1),
+            "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "warmup": warmup,
+            "batch_per_gpu": 16, "lr_size": [32, 32], "hr_size": [128, 128], "optimizer": "Adam(1e-4)",
+            "generator_tflops": round(world * flop * steps / el / 1e12, 1),
+            "scope": "G forward + L1 + backward + Adam only; discriminator and VGG terms of the adversarial step "
+                     "are not part of this number"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=128, help="LR patch height = width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the extra training-step figure")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="batch parts the forward runs on concurrent HIP streams (0 = library default, 2); "
+                         "1 serialises the kernels, which is what a per-kernel profile needs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +231,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.streams > 0:
+        os.environ["SR355_STREAMS"] = str(args.streams)      # read once, when the library first runs a forward
     import super_resolution_amd as S
     torch.manual_seed(0)
     net = S.GeneratorRRDB(precision="bf16").to(dev).eval()
@@ -205,7 +267,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"configs[1]: RRDBNet x4 (nf=64, 23 RRDB) bf16 inference, batch {B} of 3x{H}x{W} "
                                f"LR patches per GPU -> 3x{4 * H}x{4 * W}, inputs resident in HBM",
-                   "batch_per_gpu": B, "lr_size": [H, W], "parallelism": f"patch-sharded x{world}, no collective"},
+                   "batch_per_gpu": B, "lr_size": [H, W], "parallelism": f"patch-sharded x{world}, no collective",
+                   "streams_per_gpu": args.streams if args.streams > 0 else 2},
         "generator_tflops": round(world * B * H * W * FLOP_PER_LR_PIXEL * args.steps / elapsed / 1e12, 1),
     }
     if rank == 0 and world == 1:
@@ -217,6 +280,12 @@ def main():
             line["kernel_shapes"] = per_shape
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W)
+    if not args.no_train:
+        del out
+        try:
+            line["train"] = train_rate(dev, world, dist)
+        except Exception as exc:      # the headline number above stands on its own
+            line["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsr355.so")
+# SR355_LIB names another build of the same ABI (A/B measurements of kernel changes)
+LIB_PATH = os.environ.get("SR355_LIB") or os.path.join(_HERE, "libsr355.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0

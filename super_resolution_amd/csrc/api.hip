@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "sr355_internal.h"
@@ -438,6 +439,44 @@ static ConvArgs conv_args_zero() {
     return a;
 }
 
+// Second stream of a device for the two-stream forward (created on first use, never destroyed) and the
+// fork/join events around it.
+constexpr int MAX_PARTS = 4;
+struct SideStream {
+    hipStream_t stream[MAX_PARTS - 1] = {};
+    hipEvent_t fork = nullptr, join[MAX_PARTS - 1] = {};
+    std::mutex in_use;   // held while one forward issues its launches: the events are not reentrant
+};
+
+static SideStream *side_stream() {
+    static SideStream per_dev[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SideStream &ss = per_dev[dev];
+    if (!ss.fork) {
+        for (int i = 0; i < MAX_PARTS - 1; ++i)
+            if (hipStreamCreateWithFlags(&ss.stream[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ss.join[i], hipEventDisableTiming) != hipSuccess)
+                return nullptr;
+        if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &ss;
+}
+
+// Images are independent and every buffer is image-major, so a batch can run as several part-batches
+// on as many streams: one part's kernels fill the launch gaps, prologues and store bursts of the
+// others'.  Worth it only while each part still fills the chip; returns the number of parts.
+static int batch_parts(int N, int H, int W) {
+    static const int knob = [] { const char *e = getenv("SR355_STREAMS"); return e ? atoi(e) : 2; }();
+    int parts = knob < 1 ? 1 : (knob > MAX_PARTS ? MAX_PARTS : knob);
+    if (parts > N) parts = N;
+    const long long tiles_img = (long long)((W + 31) / 32) * ((H + 7) / 8);
+    while (parts > 1 && (N / parts) * tiles_img < 256) --parts;
+    return parts;
+}
+
 static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpec> &specs, const unsigned char *pk,
                        const float *in_nchw, float *out_nchw, int N, int H, int W, const Workspace &ws,
                        const FwdBufs &fb, hipStream_t stream) {
@@ -448,34 +487,63 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                                     specs[0].split == SR355_SPLIT_INPUT, stream);
     if (rc) return rc;
 
+    // parts of the batch and the stream each runs on
+    int n_parts = dtype == SR355_DTYPE_BF16 ? batch_parts(N, H, W) : 1;
+    int part_n0[MAX_PARTS] = {0}, part_n[MAX_PARTS] = {N};
+    hipStream_t part_stream[MAX_PARTS] = {stream};
+    SideStream *ss = n_parts > 1 ? side_stream() : nullptr;
+    if (!ss) n_parts = 1;
+    std::unique_lock<std::mutex> side_lock;
+    if (ss) {
+        side_lock = std::unique_lock<std::mutex>(ss->in_use);
+        if (check_hip(hipEventRecord(ss->fork, stream), "hipEventRecord")) return SR355_ERR_HIP;
+        for (int p = 0; p < n_parts; ++p) {
+            part_n0[p] = (int)((long long)N * p / n_parts);
+            part_n[p] = (int)((long long)N * (p + 1) / n_parts) - part_n0[p];
+            if (p > 0) {
+                part_stream[p] = ss->stream[p - 1];
+                if (check_hip(hipStreamWaitEvent(part_stream[p], ss->fork, 0), "hipStreamWaitEvent"))
+                    return SR355_ERR_HIP;
+            }
+        }
+    }
+
     size_t ci = 0;  // running conv index
     auto conv = [&](const unsigned char *in, int in_units, int cin_units, int h, int w, int ups,
                     unsigned char *out_act, int out_units, int out_off, float slope, const float *res1, float s1,
                     const float *res2, float s2, float *out_f32, float *out_nc) -> int {
         const ConvSpec &sp = specs[ci++];
-        ConvArgs a = conv_args_zero();
-        a.in = in;
-        a.w = pk + sp.w_off;
-        a.bias = (const float *)(pk + sp.b_off);
-        a.out_act = out_act;
-        a.out_f32 = out_f32;
-        a.out_nchw = out_nc;
-        a.res1 = res1;
-        a.res2 = res2;
-        a.res1_scale = s1;
-        a.res2_scale = s2;
-        a.slope = slope;
-        a.N = N;
-        a.H = h;
-        a.W = w;
-        a.in_units = in_units;
-        a.ups = ups;
-        a.out_units = out_units;
-        a.out_unit_off = out_off;
-        a.cout_real = sp.cout;
-        a.cout_pad = cout_pad_for(sp.cout);
-        a.f32_units = sp.cout / 4;
-        return launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, stream);
+        const size_t in_img = (size_t)(h >> ups) * (w >> ups) * in_units * 16;
+        const size_t act_img = (size_t)h * w * out_units * 16;
+        const size_t f32_img = (size_t)h * w * sp.cout;   // floats
+        for (int p = 0; p < n_parts; ++p) {
+            const size_t n0 = (size_t)part_n0[p];
+            ConvArgs a = conv_args_zero();
+            a.in = in + n0 * in_img;
+            a.w = pk + sp.w_off;
+            a.bias = (const float *)(pk + sp.b_off);
+            a.out_act = out_act ? out_act + n0 * act_img : nullptr;
+            a.out_f32 = out_f32 ? out_f32 + n0 * f32_img : nullptr;
+            a.out_nchw = out_nc ? out_nc + n0 * f32_img : nullptr;
+            a.res1 = res1 ? res1 + n0 * f32_img : nullptr;
+            a.res2 = res2 ? res2 + n0 * f32_img : nullptr;
+            a.res1_scale = s1;
+            a.res2_scale = s2;
+            a.slope = slope;
+            a.N = part_n[p];
+            a.H = h;
+            a.W = w;
+            a.in_units = in_units;
+            a.ups = ups;
+            a.out_units = out_units;
+            a.out_unit_off = out_off;
+            a.cout_real = sp.cout;
+            a.cout_pad = cout_pad_for(sp.cout);
+            a.f32_units = sp.cout / 4;
+            const int rc_ = launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, part_stream[p]);
+            if (rc_) return rc_;
+        }
+        return SR355_OK;
     };
 
     int bi = 0;  // dense-block buffer index
@@ -518,8 +586,15 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     if ((rc = conv(fb.H2, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, fb.H3, ws.nf_units, 0, 0.2f, nullptr, 0.f,
                    nullptr, 0.f, nullptr, nullptr)))
         return rc;
-    return conv(fb.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f, nullptr, 0.f,
-                nullptr, out_nchw);
+    rc = conv(fb.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f, nullptr, 0.f,
+              nullptr, out_nchw);
+    if (rc) return rc;
+    for (int p = 1; p < n_parts; ++p) {   // join: the caller's stream continues after every part
+        if (check_hip(hipEventRecord(ss->join[p - 1], part_stream[p]), "hipEventRecord") ||
+            check_hip(hipStreamWaitEvent(stream, ss->join[p - 1], 0), "hipStreamWaitEvent"))
+            return SR355_ERR_HIP;
+    }
+    return SR355_OK;
 }
 
 static int forward_checks(const char *who, const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,

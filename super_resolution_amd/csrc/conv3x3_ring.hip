@@ -19,6 +19,16 @@
 
 namespace sr355 {
 
+// Timeline instrumentation (tools/trace_conv): with -DSR355_TRACE every workgroup stamps the 100 MHz wall
+// clock at fixed points of its life into 16 slots of the buffer this pointer names.
+unsigned long long *g_conv_trace = nullptr;
+#ifdef SR355_TRACE
+#define SR355_STAMP(K)                                                                                \
+    if (a.trace && threadIdx.x == 0) a.trace[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (K)] = wall_clock64();
+#else
+#define SR355_STAMP(K)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -56,6 +66,7 @@ template <int MB, int NB, int WAVES, int R, int WPS>
 __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a) {
     typedef RingGeo<MB, NB, WAVES, R> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SR355_STAMP(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
     if (n_my > 0) SR355_TILE_SETUP(0);
 #pragma unroll
     for (int g = 0; g < R - 1; ++g) SR355_ISSUE_STAGE(g);
+    SR355_STAMP(1);
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
         // after the barrier it has landed for every wave, and slot (g-1)%R is free to refill.
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G::KMIN) : "memory");
         __builtin_amdgcn_s_barrier();
+        if (g == 0) SR355_STAMP(2);
         const unsigned char *buf = smem + slot * G::STAGE_BYTES;
         const unsigned char *pin = buf + lane_in;
         const unsigned char *pw = buf + lane_w;
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
 
         if (++ct_stage == S) {
             // ---- epilogue of tile ct_tile ----
+            if (ct_tile < 6) SR355_STAMP(3 + 2 * ct_tile);
             const int t = first + ct_tile * nwg;
             const int tx_i = t % a.tiles_x;
             const int tr = t / a.tiles_x;
@@ -253,11 +267,13 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
                 }
             }
             ct_stage = 0;
+            if (ct_tile < 6) SR355_STAMP(4 + 2 * ct_tile);
             ++ct_tile;
         }
     }
     // drain the DMA still in flight (dummy stages) before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SR355_STAMP(15);
 #undef SR355_TILE_SETUP
 #undef SR355_ISSUE_STAGE
 #undef SR355_LOAD_FRAGS
@@ -312,6 +328,7 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
     static const int dbg = [] { const char *e = getenv("SR355_DEBUG"); return e ? atoi(e) : 0; }();
     static const int var = [] { const char *e = getenv("SR355_VARIANT"); return e ? atoi(e) : 5; }();
     b.debug = dbg;
+    b.trace = g_conv_trace;
     const bool wide = (a.cout_pad % 64) == 0;
     if (var == 1) {   // 4 waves x 4 rows, two workgroups per CU, one stage in flight each
         return wide ? launch_ring_inst<2, 4, 4, 2>(b, stream) : launch_ring_inst<1, 4, 4, 2>(b, stream);

@@ -36,6 +36,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int rotate;                  // ring kernel: 1 = per-tile rotation of the stage order
     int debug;                   // timing experiments only: bit 0 = skip reads, bit 1 = skip stores
+    unsigned long long *trace;   // timing experiments only: 16 wall-clock stamps per workgroup, normally null
 };
 
 void set_error(const char *fmt, ...);

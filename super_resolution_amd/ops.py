@@ -111,16 +111,14 @@ def _(w, bias, dtype, split=0):
     return (w.new_empty(cu * 9 * cp * 16, dtype=torch.uint8), w.new_empty(cp, dtype=torch.float32))
 
 
-@torch.library.custom_op("sr355::conv3x3_fwd", mutates_args=("out_act", "out_f32", "out_nchw"))
-def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Tensor, cout: int,
-                lrelu_slope: float, upsample: int,
-                res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
-                out_act: Optional[Tensor], out_unit_off: int,
-                out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
-                mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
-                res1_weight: float = 1.0, res2_weight: float = 1.0) -> None:
-    """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, sign mask,
-    weighted skips and optional nearest-x2 upsample of the input; writes any subset of the outputs."""
+def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Tensor, cout: int,
+              lrelu_slope: float, upsample: int,
+              res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
+              out_act: Optional[Tensor], out_unit_off: int,
+              out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
+              mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
+              res1_weight: float = 1.0, res2_weight: float = 1.0) -> ConvArgs:
+    """The sr355_conv_args record for one conv launch (the tensors must outlive its use)."""
     _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw, mask)
     a = ConvArgs()
     a.dtype = _CODE[in_buf.dtype]
@@ -154,8 +152,29 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
     a.out_unit_off = int(out_unit_off)
     a.out_f32_dev = _ptr(out_f32)
     a.out_nchw_dev, a.out_nchw_bytes = _ptr(out_nchw), _nbytes(out_nchw)
+    return a
+
+
+def launch_conv(a: ConvArgs) -> None:
+    """sr355_conv3x3_fwd on the current device's current stream."""
+    check(_lib.lib().sr355_conv3x3_fwd(C.byref(a), _stream()), "sr355_conv3x3_fwd")
+
+
+@torch.library.custom_op("sr355::conv3x3_fwd", mutates_args=("out_act", "out_f32", "out_nchw"))
+def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Tensor, cout: int,
+                lrelu_slope: float, upsample: int,
+                res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor], res2_scale: float,
+                out_act: Optional[Tensor], out_unit_off: int,
+                out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
+                mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
+                res1_weight: float = 1.0, res2_weight: float = 1.0) -> None:
+    """3x3/s1/p1 conv over units [0, cin_units) of ``in_buf`` with fused bias, LeakyReLU, sign mask,
+    weighted skips and optional nearest-x2 upsample of the input; writes any subset of the outputs."""
+    a = conv_args(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale,
+                  res2, res2_scale, out_act, out_unit_off, out_f32, out_nchw, weight_split, mask, mask_unit_off,
+                  mask_slope, res1_weight, res2_weight)
     with torch.cuda.device(in_buf.device):
-        check(_lib.lib().sr355_conv3x3_fwd(C.byref(a), _stream()), "sr355_conv3x3_fwd")
+        launch_conv(a)
 
 
 @conv3x3_fwd.register_fake

@@ -9,6 +9,7 @@ timeout -k 10 400 python -u bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/
 rc=$?; echo "bench_exit=$rc"; cat gpurun_out/bench_$TAG.json; tail -n 5 gpurun_out/bench_$TAG.err
 if [ $rc -ne 0 ]; then exit $rc; fi
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_$TAG.log 2>&1
-rc=$?; echo "prof_exit=$rc"; tail -n 3 gpurun_out/prof_$TAG.log
+# per-kernel summary: kernels serialised (one stream), so a kernel's average duration is its own
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --streams 1 --no-cpu-baseline --no-train > gpurun_out/prof_$TAG.log 2>&1
+rc=$?; echo "prof_exit=$rc"; tail -n 2 gpurun_out/prof_$TAG.log | cut -c1-1500
 find gpurun_out/prof_$TAG -name "*stats*" | head
