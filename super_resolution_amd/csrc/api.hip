@@ -401,16 +401,16 @@ int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_p
         return SR355_ERR_INVALID;
     }
     unsigned char *base = (unsigned char *)packed;
+    std::vector<PackJob> jobs(specs.size());
     for (size_t i = 0; i < specs.size(); ++i) {
         if (!w_ptrs[i] || !b_ptrs[i]) {
             set_error("generator_pack: tensor %zu is null", i);
             return SR355_ERR_INVALID;
         }
-        int rc = launch_pack_weight(w_ptrs[i], b_ptrs[i], specs[i].cout, specs[i].cin, cfg->dtype, specs[i].split,
-                                    base + specs[i].w_off, (float *)(base + specs[i].b_off), (hipStream_t)stream);
-        if (rc) return rc;
+        jobs[i] = PackJob{w_ptrs[i], b_ptrs[i], base + specs[i].w_off, (float *)(base + specs[i].b_off), specs[i].cout,
+                          specs[i].cin, specs[i].split};
     }
-    return SR355_OK;
+    return launch_pack_weight_batch(jobs.data(), (int)jobs.size(), cfg->dtype, (hipStream_t)stream);
 }
 
 size_t sr355_generator_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
@@ -773,6 +773,13 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
     unsigned char *base = (unsigned char *)packed;
     // zero the whole blob once: padded input units (conv_last) and the shared bias must read as zero
     if (check_hip(hipMemsetAsync(base, 0, bp.total, stream), "hipMemsetAsync")) return SR355_ERR_HIP;
+    std::vector<PackTJob> jobs;
+    jobs.reserve((size_t)45 * nb + 6);
+    auto launch_pack_weight_t = [&jobs](const float *w, int Co, int Ci, int ci_lo, int n_out, int, float scale, void *wp,
+                                        int unit_off, int cout_pad, hipStream_t) -> int {
+        jobs.push_back(PackTJob{w, wp, Co, Ci, ci_lo, n_out, unit_off, cout_pad, scale});
+        return SR355_OK;
+    };
     int rc;
     for (int i = 0; i < 3 * nb; ++i) {
         const float *const *w = w_ptrs + 1 + (size_t)i * 5;   // conv1..conv5 of dense block i
@@ -799,8 +806,10 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
     if ((rc = launch_pack_weight_t(tail[4], cfg->out_channels, nf, 0, nf, dt, 1.f, base + bp.last, 0, cout_pad_for(nf),
                                    stream)))
         return rc;
-    return launch_pack_weight_t(w_ptrs[0], nf, cfg->in_channels, 0, cfg->in_channels, dt, 1.f, base + bp.first, 0,
-                                cout_pad_for(cfg->in_channels), stream);
+    if ((rc = launch_pack_weight_t(w_ptrs[0], nf, cfg->in_channels, 0, cfg->in_channels, dt, 1.f, base + bp.first, 0,
+                                   cout_pad_for(cfg->in_channels), stream)))
+        return rc;
+    return launch_pack_weight_t_batch(jobs.data(), (int)jobs.size(), dt, stream);
 }
 
 // Backward workspace.

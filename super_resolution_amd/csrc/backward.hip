@@ -35,8 +35,8 @@ template <> __device__ __forceinline__ __bf16 cvt<__bf16>(float v) { return (__b
 // The destination is a packed tensor [units][9][cout_pad][unit]; this call fills units
 // [unit_off, unit_off + ceil(Co / unit)).
 template <typename T>
-__global__ void pack_weight_t_kernel(const float *__restrict__ w, T *__restrict__ wp, int Co, int Ci, int ci_lo,
-                                     int n_out, int unit_off, int cout_pad, float scale) {
+__device__ __forceinline__ void pack_weight_t_body(const float *__restrict__ w, T *__restrict__ wp, int Co, int Ci,
+                                                   int ci_lo, int n_out, int unit_off, int cout_pad, float scale) {
     constexpr int CPU = 16 / sizeof(T);
     const int units = (Co + CPU - 1) / CPU;
     const int total = units * 9 * cout_pad;
@@ -57,6 +57,23 @@ __global__ void pack_weight_t_kernel(const float *__restrict__ w, T *__restrict_
         __builtin_memcpy(&pk, v, 16);
         reinterpret_cast<uint4 *>(wp)[((size_t)(unit_off + u) * 9 + tap) * cout_pad + o] = pk;
     }
+}
+
+template <typename T>
+__global__ void pack_weight_t_kernel(const float *__restrict__ w, T *__restrict__ wp, int Co, int Ci, int ci_lo,
+                                     int n_out, int unit_off, int cout_pad, float scale) {
+    pack_weight_t_body<T>(w, wp, Co, Ci, ci_lo, n_out, unit_off, cout_pad, scale);
+}
+
+struct PackTJobTable {
+    PackTJob j[PACK_BATCH];
+};
+
+// blockIdx.y = job; the blocks of a row stride over that job's items
+template <typename T>
+__global__ void pack_weight_t_batch_kernel(const PackTJobTable t) {
+    const PackTJob &j = t.j[blockIdx.y];
+    pack_weight_t_body<T>(j.w, (T *)j.wp, j.Co, j.Ci, j.ci_lo, j.n_out, j.unit_off, j.cout_pad, j.scale);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -126,6 +143,7 @@ struct WgradArgs {
     const unsigned char *in;   // blocked bf16 activations (conv input)
     const unsigned char *dy;   // blocked bf16 gradient of the conv output
     float *slabs;              // [chunks][G][9][CO][32]
+    float *bias_slabs;         // [G][CO] per-workgroup sums of dy over its pixels, or null
     int N, H, W;               // output-resolution dims
     int in_units, ups;         // input geometry (ups: input at half resolution, nearest x2)
     int dy_units, dy_unit_off;
@@ -235,6 +253,17 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[kx][mb][e] = 0.f;
+    // Bias gradient = dy summed over pixels = dy x ones: wave 0 of the first channel chunk spends one more
+    // MFMA per dy fragment on it (every column of the product holds the sum).
+    const bool do_bias = a.bias_slabs && chunk == 0 && wave == 0;
+    f32x16 accb[MB];
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[mb][e] = 0.f;
 
     // transposing-read lane geometry: 16-lane group g reads a 4-pixel x 16-channel block; lane 4q+p of
     // the group supplies the address of pixel q, channels 4p..4p+3, and receives channel (lane & 15).
@@ -277,6 +306,11 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
                         acc[kx][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[kx], acc[kx][mb], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        accb[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], ones, accb[mb], 0, 0, 0);
+                }
             }
         }
         slot ^= 1;
@@ -295,6 +329,13 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
                 const int rowc = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 slab[((wave * 3 + kx) * G::CO + rowc) * 32 + col] = acc[kx][mb][e];
             }
+    if (do_bias && col == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                a.bias_slabs[(size_t)blockIdx.x * G::CO + mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = accb[mb][e];
+    }
 }
 
 #undef SR355_WG_SETUP
@@ -305,11 +346,21 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
 __global__ __launch_bounds__(192) void wgrad3x3_kernel_mb1(const WgradArgs a) { wgrad3x3_body<1>(a); }
 __global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { wgrad3x3_body<2>(a); }
 
-// dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32]
+// dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32], and, when db is given,
+// db[co] (=|+=) scale * sum_g bias_slab[g][co]; a fixed summation order, so results are reproducible.
 __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int cout, int cin, int CO,
-                                    int G, float scale, int accumulate) {
-    const int total = 9 * cout * cin;
+                                    int G, float scale, int accumulate, const float *__restrict__ bias_slabs,
+                                    float *__restrict__ db) {
+    const int n_w = 9 * cout * cin;
+    const int total = n_w + (db ? cout : 0);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i >= n_w) {
+            const int co = i - n_w;
+            float sum = 0.f;
+            for (int gidx = 0; gidx < G; ++gidx) sum += bias_slabs[(size_t)gidx * CO + co];
+            db[co] = accumulate ? db[co] + scale * sum : scale * sum;
+            continue;
+        }
         const int ci = i % cin;
         const int t = i / cin;
         const int co = t % cout;
@@ -319,39 +370,6 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__re
         for (int gidx = 0; gidx < G; ++gidx) sum += s[(size_t)gidx * 9 * CO * 32];
         float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
         *d = accumulate ? *d + scale * sum : scale * sum;
-    }
-}
-
-// db[c] (=|+=) scale * sum over pixels of dy[c]; one workgroup per unit of 8 channels.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const __bf16 *__restrict__ dy, int N, int H, int W, int dy_units,
-                                                         int dy_unit_off, int cout, float scale, float *__restrict__ db,
-                                                         int accumulate) {
-    __shared__ float red[256][8];
-    const int u = blockIdx.x;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const size_t rows = (size_t)N * H;
-    for (size_t rr = threadIdx.x / 32; rr < rows; rr += 8) {
-        const __bf16 *base = dy + ((rr * dy_units + dy_unit_off + u) * W) * 8;
-        for (int x = threadIdx.x % 32; x < W; x += 32) {
-            uint4 pk = reinterpret_cast<const uint4 *>(base)[x];
-            __bf16 v[8];
-            __builtin_memcpy(v, &pk, 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + s][e];
-        __syncthreads();
-    }
-    if (threadIdx.x < 8) {
-        const int c = u * 8 + threadIdx.x;
-        if (c < cout) db[c] = accumulate ? db[c] + scale * red[0][threadIdx.x] : scale * red[0][threadIdx.x];
     }
 }
 
@@ -372,6 +390,20 @@ int launch_pack_weight_t(const float *w, int Co, int Ci, int ci_lo, int n_out, i
         hipLaunchKernelGGL(pack_weight_t_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, (float *)wp, Co,
                            Ci, ci_lo, n_out, unit_off, cout_pad, scale);
     return check_hip(hipGetLastError(), "pack_weight_t launch");
+}
+
+int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream_t stream) {
+    for (int at = 0; at < n; at += PACK_BATCH) {
+        PackTJobTable t;
+        const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
+        for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
+        if (dtype == SR355_DTYPE_BF16)
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<__bf16>, dim3(8, m), dim3(256), 0, stream, t);
+        else
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<float>, dim3(8, m), dim3(256), 0, stream, t);
+        if (check_hip(hipGetLastError(), "pack_weight_t batch launch")) return SR355_ERR_HIP;
+    }
+    return SR355_OK;
 }
 
 int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const void *mask, int mask_units,
@@ -404,7 +436,8 @@ void wgrad_geometry(int cin, int N, int H, int W, int *chunks, int *G) {
 size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
     int chunks, G;
     wgrad_geometry(cin, N, H, W, &chunks, &G);
-    return (size_t)chunks * G * 9 * cout_pad_for(cout) * 32 * sizeof(float);
+    // weight slabs, then one row of per-workgroup bias sums
+    return ((size_t)chunks * G * 9 * 32 + G) * cout_pad_for(cout) * sizeof(float);
 }
 
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
@@ -421,6 +454,7 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     a.in = (const unsigned char *)in;
     a.dy = (const unsigned char *)dy;
     a.slabs = slabs;
+    a.bias_slabs = db ? slabs + (size_t)chunks * G * 9 * co_pad * 32 : nullptr;
     a.N = N, a.H = H, a.W = W;
     a.in_units = in_units, a.ups = ups;
     a.dy_units = dy_units, a.dy_unit_off = dy_unit_off;
@@ -445,14 +479,9 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     else
         hipLaunchKernelGGL(wgrad3x3_kernel_mb1, grid, dim3(192), WGeo<1>::LDS_BYTES, stream, a);
     if (check_hip(hipGetLastError(), "wgrad3x3 launch")) return SR355_ERR_HIP;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)9 * cout * cin)), dim3(256), 0, stream, slabs, dw,
-                       cout, cin, co_pad, G, scale, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)9 * cout * cin + cout)), dim3(256), 0, stream, slabs,
+                       dw, cout, cin, co_pad, G, scale, accumulate, a.bias_slabs, db);
     if (check_hip(hipGetLastError(), "wgrad reduce launch")) return SR355_ERR_HIP;
-    if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3((cout + 7) / 8), dim3(256), 0, stream, (const __bf16 *)dy, N, H, W,
-                           dy_units, dy_unit_off, cout, scale, db, accumulate);
-        if (check_hip(hipGetLastError(), "bias grad launch")) return SR355_ERR_HIP;
-    }
     return SR355_OK;
 }
 

@@ -71,9 +71,9 @@ __global__ void blocked_to_nchw_kernel(const T *__restrict__ src, float *__restr
 // the rounding residue w - round(w).  SR355_SPLIT_INPUT additionally repeats the rounded weights on
 // channels [cin, 2cin) of image 0, where the input carries its own residue.
 template <typename T>
-__global__ void pack_weight_kernel(const float *__restrict__ w, const float *__restrict__ bias,
-                                   T *__restrict__ wp, float *__restrict__ bp, int cout, int cin,
-                                   int U, int cout_pad, int split) {
+__device__ __forceinline__ void pack_weight_body(const float *__restrict__ w, const float *__restrict__ bias,
+                                                 T *__restrict__ wp, float *__restrict__ bp, int cout, int cin,
+                                                 int U, int cout_pad, int split) {
     constexpr int CPU = 16 / sizeof(T);
     const int total = U * (split ? 2 : 1) * 9 * cout_pad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -100,6 +100,28 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, const float *__r
         reinterpret_cast<uint4 *>(wp)[i] = pk;
         if (i < cout_pad && bp) bp[i] = (i < cout && bias) ? bias[i] : 0.f;
     }
+}
+
+template <typename T>
+__global__ void pack_weight_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                   T *__restrict__ wp, float *__restrict__ bp, int cout, int cin,
+                                   int U, int cout_pad, int split) {
+    pack_weight_body<T>(w, bias, wp, bp, cout, cin, U, cout_pad, split);
+}
+
+struct PackJobTable {
+    PackJob j[PACK_BATCH];
+};
+
+// blockIdx.y = job; the blocks of a row stride over that job's items
+template <typename T>
+__global__ void pack_weight_batch_kernel(const PackJobTable t) {
+    const PackJob &j = t.j[blockIdx.y];
+    constexpr int CPU = 16 / sizeof(T);
+    const int split = sizeof(T) == 2 ? j.split : 0;   // only the bf16 path carries rounding residues
+    const int real = split == SR355_SPLIT_INPUT ? 2 * j.cin : j.cin;
+    const int U = ((real + CPU - 1) / CPU + 1) / 2 * 2;   // whole stages of two units
+    pack_weight_body<T>(j.w, j.bias, (T *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, split);
 }
 
 static unsigned grid_for(size_t total) {
@@ -142,6 +164,20 @@ int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, w, bias,
                            (float *)wp, bp, cout, cin, cu, cp, 0);
     return check_hip(hipGetLastError(), "pack_weight launch");
+}
+
+int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t stream) {
+    for (int at = 0; at < n; at += PACK_BATCH) {
+        PackJobTable t;
+        const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
+        for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
+        if (dtype == SR355_DTYPE_BF16)
+            hipLaunchKernelGGL(pack_weight_batch_kernel<__bf16>, dim3(16, m), dim3(256), 0, stream, t);
+        else
+            hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(16, m), dim3(256), 0, stream, t);
+        if (check_hip(hipGetLastError(), "pack_weight batch launch")) return SR355_ERR_HIP;
+    }
+    return SR355_OK;
 }
 
 }  // namespace sr355

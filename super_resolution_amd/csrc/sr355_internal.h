@@ -55,6 +55,24 @@ int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dty
 int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,
                        void *wp, float *bp, hipStream_t stream);
 
+// Batched weight packing: up to PACK_BATCH jobs travel in the kernel arguments of one launch
+// (a training step repacks every conv after the optimizer update: ~350 forward and ~1000 transposed packs).
+constexpr int PACK_BATCH = 64;
+struct PackJob {      // one launch_pack_weight call
+    const float *w, *bias;
+    void *wp;
+    float *bp;
+    int cout, cin, split;
+};
+struct PackTJob {     // one launch_pack_weight_t call
+    const float *w;
+    void *wp;
+    int Co, Ci, ci_lo, n_out, unit_off, cout_pad;
+    float scale;
+};
+int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t stream);
+int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream_t stream);
+
 // ---- backward.hip ----
 int launch_pack_weight_t(const float *w, int Co, int Ci, int ci_lo, int n_out, int dtype, float scale, void *wp,
                          int unit_off, int cout_pad, hipStream_t stream);
