@@ -230,19 +230,130 @@ def discriminator_layout(base: int = 64) -> List[Tuple[int, int, int, int, Optio
 
 
 def discriminator_forward(sd: StateDict, img: torch.Tensor, training: bool, base: int = 64,
-                          momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+                          momentum: float = 0.1, eps: float = 1e-5, emulate_bf16: bool = False) -> torch.Tensor:
+    """``emulate_bf16`` (not reference behaviour) rounds every conv's weights and input to bf16, the rounding
+    points of the HIP path (conv outputs feed BatchNorm in fp32 there)."""
     x = img
     layout = discriminator_layout(base)
     for j, (ci, _cin, _cout, stride, bi) in enumerate(layout):
-        x = F.conv2d(x, sd[f"model.{ci}.weight"], sd[f"model.{ci}.bias"], stride=stride, padding=1)
+        w = sd[f"model.{ci}.weight"]
+        if emulate_bf16:
+            w, x = _bf16r(w), _bf16r(x)
+        x = F.conv2d(x, w, sd[f"model.{ci}.bias"], stride=stride, padding=1)
         if j == len(layout) - 1:
             break
         if bi is not None:
+            if training and f"model.{bi}.num_batches_tracked" in sd:      # nn.BatchNorm2d counts training forwards
+                sd[f"model.{bi}.num_batches_tracked"] += 1
             x = F.batch_norm(x, sd[f"model.{bi}.running_mean"], sd[f"model.{bi}.running_var"],
                              sd[f"model.{bi}.weight"], sd[f"model.{bi}.bias"],
                              training=training, momentum=momentum, eps=eps)
         x = F.leaky_relu(x, LRELU_SLOPE)
     return x
+
+
+# --------------------------------------------------------------------------
+# VGG19 feature extractor (esrgan_model.py:90-103 -> torchvision vgg19.features[:35])
+# --------------------------------------------------------------------------
+# torchvision is a third-party dependency of the reference (requirements.txt, unpinned) and is not
+# installed here, and its ImageNet weights cannot be fetched: the ARITHMETIC below restates torchvision's
+# published vgg19 configuration 'E' (conv3x3+ReLU stacks with 2x2 max pools; features[:35] ends with
+# conv5_4 before its ReLU); parity of the VGG numbers against torchvision itself is unpinned.
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
+
+
+def vgg19_layout(feature_layer: int = 35) -> List[Tuple[str, int, int, int]]:
+    """[(kind, index, cin, cout)] of features[:feature_layer]; kind in {"conv", "relu", "pool"}."""
+    out, idx, cin = [], 0, 3
+    for v in VGG19_CFG:
+        if v == "M":
+            out.append(("pool", idx, cin, cin))
+            idx += 1
+        else:
+            out.append(("conv", idx, cin, v))
+            out.append(("relu", idx + 1, v, v))
+            idx += 2
+            cin = v
+    return out[:feature_layer]
+
+
+def make_vgg_state(seed: int, feature_layer: int = 35) -> StateDict:
+    """Seeded stand-in weights with the reference's keys (features.N.weight / .bias): He-normal over the
+    fan-out as torchvision initialises an untrained vgg19, zero biases."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = OrderedDict()
+    for kind, idx, cin, cout in vgg19_layout(feature_layer):
+        if kind == "conv":
+            std = math.sqrt(2.0 / (cout * 9))
+            sd[f"features.{idx}.weight"] = torch.randn(cout, cin, 3, 3, generator=gen) * std
+            sd[f"features.{idx}.bias"] = torch.zeros(cout)
+    return sd
+
+
+def vgg_features(sd: StateDict, x: torch.Tensor, feature_layer: int = 35, emulate_bf16: bool = False) -> torch.Tensor:
+    """``emulate_bf16`` (not reference behaviour) rounds weights and every stored activation to bf16 where the HIP
+    path does, so that ReLU signs and pooling winners are the ones that path sees."""
+    layout = vgg19_layout(feature_layer)
+    for j, (kind, idx, _cin, _cout) in enumerate(layout):
+        if kind == "conv":
+            w = sd[f"features.{idx}.weight"]
+            if emulate_bf16:
+                w, x = _bf16r(w), _bf16r(x)
+            x = F.conv2d(x, w, sd[f"features.{idx}.bias"], padding=1)
+            fused_relu = j + 1 < len(layout) and layout[j + 1][0] == "relu"
+            if emulate_bf16 and not fused_relu:
+                x = _bf16r(x)
+        elif kind == "relu":
+            x = F.relu(x)
+            if emulate_bf16:
+                x = _bf16r(x)
+        else:
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+# --------------------------------------------------------------------------
+# adversarial training iteration (esrgan/train.py:196-223), without autocast / GradScaler
+# --------------------------------------------------------------------------
+def adversarial_step(sd_g: StateDict, sd_d: StateDict, sd_v: StateDict, lr_img: torch.Tensor, hr_img: torch.Tensor,
+                     lr: float = 1e-4, betas: Tuple[float, float] = (0.9, 0.999)) -> dict:
+    """Runs the discriminator update and then the generator update exactly in the order of the reference loop
+    body, with fresh Adam optimizers.  Returns the losses, the gradients each backward left, and the parameters
+    and BatchNorm buffers after both steps."""
+    g = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in sd_g.items())
+    d = OrderedDict((k, (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and
+                         not k.split(".")[-1].startswith("running") else v.detach().clone()))
+                    for k, v in sd_d.items())
+    d_params = [v for v in d.values() if v.requires_grad]
+    opt_g = torch.optim.Adam(list(g.values()), lr=lr, betas=betas)
+    opt_d = torch.optim.Adam(d_params, lr=lr, betas=betas)
+
+    opt_d.zero_grad()
+    fake = generator_forward(g, lr_img).detach()
+    pred_real = discriminator_forward(d, hr_img, training=True)
+    pred_fake = discriminator_forward(d, fake, training=True)
+    loss_d = 0.5 * (F.mse_loss(pred_real, torch.ones_like(pred_real)) + F.mse_loss(pred_fake, torch.zeros_like(pred_fake)))
+    loss_d.backward()
+    grads_d = OrderedDict((k, v.grad.clone()) for k, v in d.items() if v.requires_grad)
+    opt_d.step()
+
+    opt_g.zero_grad()
+    for v in d_params:
+        v.grad = None
+    fake = generator_forward(g, lr_img)
+    pred_fake = discriminator_forward(d, fake, training=True)
+    loss_gan = F.mse_loss(pred_fake, torch.ones_like(pred_fake))
+    loss_pix = F.l1_loss(fake, hr_img)
+    loss_per = F.l1_loss(vgg_features(sd_v, fake), vgg_features(sd_v, hr_img))
+    loss_g = loss_pix + 0.01 * loss_per + 1e-3 * loss_gan
+    loss_g.backward()
+    grads_g = OrderedDict((k, v.grad.clone()) for k, v in g.items())
+    opt_g.step()
+    return {"loss_D": float(loss_d.detach()), "loss_G": float(loss_g.detach()), "loss_G_pix": float(loss_pix.detach()),
+            "loss_G_per": float(loss_per.detach()), "loss_G_gan": float(loss_gan.detach()),
+            "grads_D": grads_d, "grads_G": grads_g,
+            "state_G": OrderedDict((k, v.detach()) for k, v in g.items()),
+            "state_D": OrderedDict((k, v.detach()) for k, v in d.items())}
 
 
 # --------------------------------------------------------------------------

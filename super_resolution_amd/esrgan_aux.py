@@ -1,0 +1,192 @@
+"""Discriminator and VGG19 feature extractor of the reference on the HIP conv core, and its two training steps.
+
+Drop-ins for /root/reference/esrgan/models/esrgan_model.py:64-103: same class names, constructor
+arguments and ``state_dict`` keys (the parameters live in the same ``nn.Sequential`` containers), so
+checkpoints interchange.  Every 3x3 convolution runs through ``conv_core.conv3x3`` (the generator's MFMA
+kernels, forward / data gradient / weight gradient); BatchNorm, max pooling and stride-2 sampling are torch
+ops on views of the blocked bf16 activations, so autograd composes the backward pass.  No CPU path.
+
+``pixel_step`` / ``adversarial_step`` restate the two loop bodies of /root/reference/esrgan/train.py
+(:157-164 and :196-223) as functions of the same objects the script holds.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import conv_core as cc
+
+
+def _need_cuda(x: Tensor, who: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(f"{who} runs only on a ROCm device (got a {x.device.type} tensor)")
+
+
+class Discriminator(nn.Module):
+    """esrgan_model.py:64-87 — nine 3x3 convs (strides 1,2,1,2,1,2,1,2,1), BatchNorm on all but the first and the
+    last, LeakyReLU(0.2); [B,3,H,W] -> [B,1,H/16,W/16]."""
+
+    def __init__(self, in_channels: int = 3, base_channels: int = 64):
+        super().__init__()
+        if base_channels % 8:
+            raise ValueError("base_channels must be a multiple of 8 (whole 8-channel units)")
+
+        def conv_block(in_f, out_f, stride=1, bn=True):
+            layers = [nn.Conv2d(in_f, out_f, 3, stride, 1)]
+            if bn:
+                layers.append(nn.BatchNorm2d(out_f))
+            layers.append(nn.LeakyReLU(0.2, inplace=True))
+            return layers
+
+        b = base_channels
+        self.model = nn.Sequential(
+            *conv_block(in_channels, b, bn=False),
+            *conv_block(b, b, stride=2),
+            *conv_block(b, b * 2),
+            *conv_block(b * 2, b * 2, stride=2),
+            *conv_block(b * 2, b * 4),
+            *conv_block(b * 4, b * 4, stride=2),
+            *conv_block(b * 4, b * 8),
+            *conv_block(b * 8, b * 8, stride=2),
+            nn.Conv2d(b * 8, 1, 3, 1, 1),
+        )
+
+    def forward(self, img: Tensor) -> Tensor:
+        _need_cuda(img, "Discriminator")
+        mods = list(self.model)
+        x = cc.to_blocked(img)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            i += 1
+            if i == len(mods):                                           # final 1-channel conv, no activation
+                return cc.conv3x3(x, conv.weight, conv.bias, 1.0, nchw_out=True)
+            if isinstance(mods[i], nn.BatchNorm2d):
+                bn, act = mods[i], mods[i + 1]
+                i += 2
+                y = cc.conv3x3(x, conv.weight, conv.bias, 1.0, f32_out=True)    # fp32 into the normalisation
+                if conv.stride[0] == 2:                                  # k=3, s=2, p=1 = the s=1 result at even positions
+                    y = y[:, ::2, :, ::2]
+                v = bn(cc.f32_as_nchw(y))                                # batch statistics / running buffers as nn.BatchNorm2d
+                x = cc.nchw_as_blocked(F.leaky_relu(v, act.negative_slope))
+            else:
+                act = mods[i]
+                i += 1
+                x = cc.conv3x3(x, conv.weight, conv.bias, act.negative_slope)   # LeakyReLU fused into the conv
+                if conv.stride[0] == 2:
+                    x = x[:, ::2, :, ::2].contiguous()
+        raise RuntimeError("unreachable")
+
+
+_VGG19 = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
+
+
+def _vgg19_feature_layers() -> list:
+    layers, cin = [], 3
+    for v in _VGG19:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return layers
+
+
+class VGGFeatureExtractor(nn.Module):
+    """esrgan_model.py:90-103 — ``vgg19.features[:feature_layer]`` (default 35: up to conv5_4, before its ReLU),
+    frozen.  ``use_bn`` changes nothing, as in the reference (:94-97 build the same plain vgg19 either way).
+
+    The ImageNet weights come from torchvision as in the reference (:93); where torchvision is not installed
+    pass ``pretrained=False`` for the architecture with default-initialised weights and load a ``state_dict``
+    with the reference's keys (``features.N.weight``)."""
+
+    def __init__(self, feature_layer: int = 35, use_bn: bool = False, *, pretrained: bool = True):
+        super().__init__()
+        layers = _vgg19_feature_layers()
+        if pretrained:
+            try:
+                from torchvision import models
+            except ImportError as exc:
+                raise ImportError("VGGFeatureExtractor(pretrained=True) takes the ImageNet weights from torchvision, "
+                                  "which is not installed; use pretrained=False and load_state_dict") from exc
+            src = models.vgg19(pretrained=True).features
+            for dst, s in zip(layers, src):
+                if isinstance(dst, nn.Conv2d):
+                    dst.load_state_dict(s.state_dict())
+        self.features = nn.Sequential(*layers[:feature_layer])
+        for p in self.features.parameters():
+            p.requires_grad = False
+
+    def forward(self, x: Tensor) -> Tensor:
+        _need_cuda(x, "VGGFeatureExtractor")
+        mods = list(self.features)
+        h = cc.to_blocked(x)
+        channels = x.shape[1]
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
+            if isinstance(m, nn.Conv2d):
+                relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+                h = cc.conv3x3(h, m.weight, m.bias, 0.0 if relu else 1.0)    # ReLU = LeakyReLU with slope 0, fused
+                channels = m.out_channels
+                if relu:
+                    i += 1
+            elif isinstance(m, nn.MaxPool2d):
+                h = cc.max_pool2x2(h)
+            elif isinstance(m, nn.ReLU):
+                h = torch.relu(h)
+            else:
+                raise RuntimeError(f"unexpected layer {type(m).__name__} in the VGG feature stack")
+        return cc.from_blocked(h, channels)
+
+
+# ------------------------------------------------------------------------------------------------
+def _backward_and_step(loss: Tensor, optimizer, scaler) -> None:
+    if scaler is None:
+        loss.backward()
+        optimizer.step()
+    else:                       # train.py:161-163 / :205-207 / :220-222
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+
+
+def pixel_step(netG: nn.Module, optim_G, lr: Tensor, hr: Tensor, scaler=None) -> Dict[str, Tensor]:
+    """One iteration of the pixel-loss pre-training loop (train.py:157-163): L1(netG(lr), hr), backward, Adam."""
+    optim_G.zero_grad()
+    sr = netG(lr)
+    loss_pix = F.l1_loss(sr, hr)
+    _backward_and_step(loss_pix, optim_G, scaler)
+    return {"loss_pix": loss_pix.detach()}
+
+
+def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, optim_D, lr: Tensor, hr: Tensor,
+                     scaler_G=None, scaler_D=None) -> Dict[str, Tensor]:
+    """One iteration of the adversarial loop (train.py:196-223): the discriminator update on (hr, detached fake),
+    then the generator update with loss_G = L1 + 0.01 * L1(vgg) + 1e-3 * MSE(D(fake), 1) on a second forward."""
+    optim_D.zero_grad()
+    with torch.no_grad():
+        fake = netG(lr)
+    pred_real = netD(hr)
+    pred_fake = netD(fake)
+    loss_D = 0.5 * (F.mse_loss(pred_real, torch.ones_like(pred_real)) +
+                    F.mse_loss(pred_fake, torch.zeros_like(pred_fake)))
+    _backward_and_step(loss_D, optim_D, scaler_D)
+
+    optim_G.zero_grad()
+    fake = netG(lr)
+    pred_fake = netD(fake)
+    loss_G_gan = F.mse_loss(pred_fake, torch.ones_like(pred_fake))
+    loss_G_pix = F.l1_loss(fake, hr)
+    feat_sr = vgg(fake)
+    feat_hr = vgg(hr)
+    loss_G_per = F.l1_loss(feat_sr, feat_hr)
+    loss_G = loss_G_pix + 0.01 * loss_G_per + 1e-3 * loss_G_gan
+    _backward_and_step(loss_G, optim_G, scaler_G)
+    return {"loss_D": loss_D.detach(), "loss_G": loss_G.detach(), "loss_G_pix": loss_G_pix.detach(),
+            "loss_G_per": loss_G_per.detach(), "loss_G_gan": loss_G_gan.detach()}

@@ -6,7 +6,8 @@ generator and discriminator use only torch.nn, so an empty ``torchvision.models`
 is placed in sys.modules before loading the file by path.  Nothing of the reference's
 text is stored: fixtures hold seeds, inputs, outputs and gradients only.
 
-    cd /tmp && python /root/repo/tests/golden/make_golden.py
+    cd /tmp && python /root/repo/tests/golden/make_golden.py        # all fixtures
+    cd /tmp && python /root/repo/tests/golden/make_golden.py g8     # only g8_adversarial_step.npz
 """
 import importlib.util
 import os
@@ -55,9 +56,61 @@ def weight_sums(store: dict, module: torch.nn.Module):
             store[f"wsum/{name}"] = np.float64(p.double().sum().item())
 
 
+def make_g8(ref):
+    # G8: adversarial iteration (esrgan/train.py:196-223) with the reference generator and discriminator.
+    # The reference's VGGFeatureExtractor cannot be built here (torchvision absent, ImageNet weights need the
+    # network): the perceptual term uses the oracle's vgg19 restatement with seeded stand-in weights.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import esrgan_oracle as O
+    torch.manual_seed(6)
+    gen = ref.GeneratorRRDB(num_blocks=1)
+    torch.manual_seed(8)
+    disc = ref.Discriminator()
+    disc.train()
+    vsd = O.make_vgg_state(7)
+    g = torch.Generator().manual_seed(106)
+    lr = torch.rand(2, 3, 8, 8, generator=g)
+    hr = torch.rand(2, 3, 32, 32, generator=g)
+    optim_G = torch.optim.Adam(gen.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    optim_D = torch.optim.Adam(disc.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    mse, l1 = torch.nn.MSELoss(), torch.nn.L1Loss()
+    optim_D.zero_grad()
+    fake = gen(lr).detach()
+    pred_real = disc(hr)
+    pred_fake = disc(fake)
+    loss_D = 0.5 * (mse(pred_real, torch.ones_like(pred_real)) + mse(pred_fake, torch.zeros_like(pred_fake)))
+    loss_D.backward()
+    st = {"seed_g": 6, "seed_d": 8, "seed_vgg": 7, "lr": lr.numpy(), "hr": hr.numpy(),
+          "loss_D": np.float64(loss_D.item())}
+    for name, p in disc.named_parameters():
+        s_, a_, b_ = summarize(p.grad, stride=193)
+        st[f"d_gs/{name}"], st[f"d_gsum/{name}"], st[f"d_gabs/{name}"] = s_, a_, b_
+    optim_D.step()
+    optim_G.zero_grad()
+    fake = gen(lr)
+    pred_fake = disc(fake)
+    loss_G_gan = mse(pred_fake, torch.ones_like(pred_fake))
+    loss_G_pix = l1(fake, hr)
+    loss_G_per = l1(O.vgg_features(vsd, fake), O.vgg_features(vsd, hr))
+    loss_G = loss_G_pix + 0.01 * loss_G_per + 1e-3 * loss_G_gan
+    loss_G.backward()
+    st.update(loss_G=np.float64(loss_G.item()), loss_G_gan=np.float64(loss_G_gan.item()),
+              loss_G_pix=np.float64(loss_G_pix.item()), loss_G_per=np.float64(loss_G_per.item()))
+    put_grads(st, gen, full=("conv_first.weight", "conv_last.bias"))
+    optim_G.step()
+    st["running_mean_3"] = disc.model[3].running_mean.numpy().copy()
+    st["num_batches_tracked_3"] = np.int64(disc.model[3].num_batches_tracked.item())
+    for name, p in list(gen.state_dict().items()) + [("D." + k, v) for k, v in disc.state_dict().items()]:
+        if p.dtype.is_floating_point:
+            st[f"wsum/{name}"] = np.float64(p.double().sum().item())
+    np.savez_compressed(os.path.join(HERE, "g8_adversarial_step.npz"), **st)
+
 def main():
     ref = load_reference()
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["g8"]:          # only the newest fixture; the others are unchanged
+        make_g8(ref)
+        return
 
     # G1: one dense block ---------------------------------------------------------
     torch.manual_seed(0)
@@ -161,6 +214,8 @@ def main():
     st = {"seed": 5, "lr": lr.numpy(), "hr": hr.numpy(), "loss_pix": np.float64(loss.item())}
     put_grads(st, gen, full=("conv_first.weight", "conv_last.weight", "body.0.rdb1.conv1.bias"))
     np.savez_compressed(os.path.join(HERE, "g7_pixel_step.npz"), **st)
+
+    make_g8(ref)
 
     for fn in sorted(os.listdir(HERE)):
         print(fn, os.path.getsize(os.path.join(HERE, fn)))

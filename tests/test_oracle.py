@@ -157,3 +157,29 @@ def test_bf16_emulation_is_close_but_not_equal():
         emu = O.generator_forward(sd, x, emulate_bf16=True)
     assert not torch.equal(ref, emu)
     assert O.psnr(ref.clamp(0, 1), emu.clamp(0, 1)) > 45.0
+
+
+def test_adversarial_iteration_matches_reference_run(golden):
+    """G8: the reference generator + discriminator run through one adversarial iteration of esrgan/train.py:196-223
+    (perceptual term on the oracle's seeded vgg19 restatement, the reference's own being unbuildable offline)."""
+    g = golden("g8_adversarial_step.npz")
+    sd_g = O.make_generator_state(int(g["seed_g"]), num_blocks=1)
+    sd_d = O.make_discriminator_state(int(g["seed_d"]))
+    sd_v = O.make_vgg_state(int(g["seed_vgg"]))
+    r = O.adversarial_step(sd_g, sd_d, sd_v, torch.from_numpy(g["lr"]), torch.from_numpy(g["hr"]))
+    for k in ("loss_D", "loss_G", "loss_G_pix", "loss_G_per", "loss_G_gan"):
+        assert abs(r[k] - float(g[k])) <= 1e-5 * abs(float(g[k])) + 1e-7, k
+    for name, grad in r["grads_D"].items():
+        ref_sum, ref_abs = float(g[f"d_gsum/{name}"]), float(g[f"d_gabs/{name}"])
+        assert abs(grad.double().abs().sum().item() - ref_abs) <= 1e-4 * ref_abs + 1e-9, name
+        assert abs(grad.double().sum().item() - ref_sum) <= 1e-4 * ref_abs + 1e-9, name
+        np.testing.assert_allclose(grad.reshape(-1)[::193].numpy(), g[f"d_gs/{name}"], rtol=2e-3, atol=1e-7)
+    for name, grad in r["grads_G"].items():
+        ref_abs = float(g[f"gabs/{name}"])
+        assert abs(grad.double().abs().sum().item() - ref_abs) <= 1e-4 * ref_abs + 1e-9, name
+    np.testing.assert_allclose(r["grads_G"]["conv_first.weight"].numpy(), g["gfull/conv_first.weight"], rtol=2e-3, atol=1e-8)
+    np.testing.assert_allclose(r["state_D"]["model.3.running_mean"].numpy(), g["running_mean_3"], rtol=1e-4, atol=1e-7)
+    assert int(r["state_D"]["model.3.num_batches_tracked"]) == int(g["num_batches_tracked_3"]) == 3
+    for name, v in r["state_G"].items():          # parameters after both Adam steps
+        ref = float(g[f"wsum/{name}"])
+        assert abs(v.double().sum().item() - ref) <= 1e-5 * max(1.0, abs(ref)), name
