@@ -171,51 +171,74 @@ def cpu_baseline(H, W):
                       f"{med:.3f} s each, torch CPU threads={cores}"}
 
 
-def train_rate(dev, world, dist, steps=5, warmup=2):
-    """Extra figure beside the headline: the generator's pixel-loss training step of the reference
-    (esrgan/train.py:156-163: forward, L1 loss, backward, Adam) on 16 LR patches of 32x32 per GPU, with
-    the bucketed gradient all-reduce when more than one rank runs.  Not the full adversarial step."""
-    import super_resolution_amd as S
-    from super_resolution_amd.ddp import DistributedGenerator
-    torch.manual_seed(0)
-    net = S.GeneratorRRDB(precision="bf16").to(dev).train()
-    model = DistributedGenerator(net) if world > 1 else net
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
-    lr = torch.rand(16, 3, 32, 32, device=dev)
-    hr = torch.rand(16, 3, 128, 128, device=dev)
-
+def _timed_steps(step, dev, dist, steps, warmup):
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.l1_loss(model(lr), hr)
-        loss.backward()
-        opt.step()
-        return loss
 
     for _ in range(warmup):
         step()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step()
+        step()
     sync()
     el = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
-    assert bool(torch.isfinite(loss))
+    return el
+
+
+def train_rate(dev, world, dist, steps=5, warmup=2):
+    """Extra figures beside the headline, on 16 LR patches of 32x32 (128x128 HR) per GPU (BASELINE config 3 shapes):
+    * the pixel pre-training iteration (esrgan/train.py:157-163: G forward, L1, backward, Adam);
+    * the adversarial iteration (:196-223: D update on (hr, fake), then G update with L1 + 0.01 VGG-L1 + 1e-3 GAN loss),
+      VGG19 with seeded random weights (throughput does not depend on the weights).
+    With more than one rank the generator's gradients go through the bucketed all-reduce overlapped with its backward
+    and the discriminator's through torch's DistributedDataParallel."""
+    import super_resolution_amd as S
+    from super_resolution_amd.ddp import DistributedGenerator
+    torch.manual_seed(0)
+    netG = S.GeneratorRRDB(precision="bf16").to(dev).train()
+    modelG = DistributedGenerator(netG) if world > 1 else netG
+    optG = torch.optim.Adam(netG.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    lr = torch.rand(16, 3, 32, 32, device=dev)
+    hr = torch.rand(16, 3, 128, 128, device=dev)
+    losses = {}
+
+    def pixel():
+        losses.update(S.pixel_step(modelG, optG, lr, hr))
+
+    el = _timed_steps(pixel, dev, dist, steps, warmup)
+    assert bool(torch.isfinite(losses["loss_pix"]))
     flop = 3 * FLOP_PER_LR_PIXEL * 16 * 32 * 32          # backward = 2 forward-equivalents
-    return {"metric": "generator pixel-loss training step, patches/s", "value": round(world * 16 * steps / el, 1),
-            "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "warmup": warmup,
-            "batch_per_gpu": 16, "lr_size": [32, 32], "hr_size": [128, 128], "optimizer": "Adam(1e-4)",
-            "generator_tflops": round(world * flop * steps / el / 1e12, 1),
-            "scope": "G forward + L1 + backward + Adam only; discriminator and VGG terms of the adversarial step "
-                     "are not part of this number"}
+    out = {"pixel_step": {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
+                          "ms_per_step": round(el / steps * 1e3, 2), "generator_tflops": round(world * flop * steps / el / 1e12, 1)},
+           "steps": steps, "warmup": warmup, "batch_per_gpu": 16, "lr_size": [32, 32], "hr_size": [128, 128],
+           "optimizer": "Adam(1e-4, betas 0.9/0.999)"}
+    try:
+        netD = S.Discriminator().to(dev).train()
+        vgg = S.VGGFeatureExtractor(pretrained=False).to(dev)
+        modelD = netD
+        if world > 1:
+            modelD = torch.nn.parallel.DistributedDataParallel(netD, device_ids=[dev.index])
+        optD = torch.optim.Adam(netD.parameters(), lr=1e-4, betas=(0.9, 0.999))
+
+        def adversarial():
+            losses.update(S.adversarial_step(modelG, modelD, vgg, optG, optD, lr, hr))
+
+        el = _timed_steps(adversarial, dev, dist, steps, warmup)
+        assert bool(torch.isfinite(losses["loss_G"])) and bool(torch.isfinite(losses["loss_D"]))
+        out["adversarial_step"] = {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
+                                   "ms_per_step": round(el / steps * 1e3, 2),
+                                   "scope": "D update + G update (two G forwards, one G backward, three D forwards, "
+                                            "two D backwards, two VGG19 forwards, one VGG19 data-gradient), Adam on both"}
+    except Exception as exc:
+        out["adversarial_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def main():
