@@ -192,7 +192,51 @@ def _timed_steps(step, dev, dist, steps, warmup):
     return el
 
 
-def train_rate(dev, world, dist, steps=5, warmup=2):
+def graphed_pixel_step(dev, lr, hr, steps):
+    """The same pixel pre-training iteration captured once into a HIP graph (forward, loss, backward with its
+    side-stream weight gradients, Adam) and replayed: the host issues one launch per step."""
+    import super_resolution_amd as S
+    try:
+        torch.manual_seed(0)
+        net = S.GeneratorRRDB(precision="bf16").to(dev).train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), capturable=True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                torch.nn.functional.l1_loss(net(lr), hr).backward()
+                opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            loss = torch.nn.functional.l1_loss(net(lr), hr)
+            loss.backward()
+            opt.step()
+        before = net.conv_first.weight.detach().clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        first = float(loss.detach())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        moved = not torch.equal(before, net.conv_first.weight.detach())
+        ok = moved and float(loss.detach()) < first and bool(torch.isfinite(loss.detach()))      # replays train: the loss falls
+        return {"value": round(16 * steps / el, 1), "unit": "patches/s", "ms_per_step": round(el / steps * 1e3, 2),
+                "replays_update_the_weights_and_lower_the_loss": ok}
+    except Exception as exc:
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+
+
+def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
     """Extra figures beside the headline, on 16 LR patches of 32x32 (128x128 HR) per GPU (BASELINE config 3 shapes):
     * the pixel pre-training iteration (esrgan/train.py:157-163: G forward, L1, backward, Adam);
     * the adversarial iteration (:196-223: D update on (hr, fake), then G update with L1 + 0.01 VGG-L1 + 1e-3 GAN loss),
@@ -219,6 +263,8 @@ def train_rate(dev, world, dist, steps=5, warmup=2):
                           "ms_per_step": round(el / steps * 1e3, 2), "generator_tflops": round(world * flop * steps / el / 1e12, 1)},
            "steps": steps, "warmup": warmup, "batch_per_gpu": 16, "lr_size": [32, 32], "hr_size": [128, 128],
            "optimizer": "Adam(1e-4, betas 0.9/0.999)"}
+    if world == 1 and graph:
+        out["pixel_step_hipgraph"] = graphed_pixel_step(dev, lr, hr, steps)
     try:
         netD = S.Discriminator().to(dev).train()
         vgg = S.VGGFeatureExtractor(pretrained=False).to(dev)
@@ -251,6 +297,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the extra training-step figure")
+    ap.add_argument("--train-graph", action="store_true",
+                    help="also replay the pixel iteration from a captured HIP graph (measured slower than eager issue: "
+                         "about 3,000 graph nodes per step)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batch parts the forward runs on concurrent HIP streams (0 = library default, 2); "
                          "1 serialises the kernels, which is what a per-kernel profile needs")
@@ -325,7 +374,7 @@ def main():
     if not args.no_train:
         del out
         try:
-            line["train"] = train_rate(dev, world, dist)
+            line["train"] = train_rate(dev, world, dist, graph=args.train_graph)
         except Exception as exc:      # the headline number above stands on its own
             line["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:

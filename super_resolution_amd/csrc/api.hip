@@ -445,7 +445,8 @@ constexpr int MAX_PARTS = 4;
 struct SideStream {
     hipStream_t stream[MAX_PARTS - 1] = {};
     hipEvent_t fork = nullptr, join[MAX_PARTS - 1] = {};
-    std::mutex in_use;   // held while one forward issues its launches: the events are not reentrant
+    hipEvent_t main_mark = nullptr, side_mark[2] = {};   // backward: hand-offs between the two streams
+    std::mutex in_use;   // held while one forward / backward issues its launches: the events are not reentrant
 };
 
 static SideStream *side_stream() {
@@ -460,6 +461,10 @@ static SideStream *side_stream() {
             if (hipStreamCreateWithFlags(&ss.stream[i], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ss.join[i], hipEventDisableTiming) != hipSuccess)
                 return nullptr;
+        if (hipEventCreateWithFlags(&ss.main_mark, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.side_mark[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.side_mark[1], hipEventDisableTiming) != hipSuccess)
+            return nullptr;
         if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
     return &ss;
@@ -950,13 +955,35 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
             o += (size_t)specs[i].cout * specs[i].cin * 9 + specs[i].cout;
         }
     }
+    // The weight gradients depend on the data-gradient chain but nothing depends on them: they run on a side
+    // stream beside the chain (a data gradient at training sizes fills a fraction of the chip).  Every wgrad
+    // waits for what the main stream has issued so far; the main stream waits for a dense block's wgrads
+    // before it overwrites the gradient stack they read (one block later), and for all of them at the end.
+    static const int side_knob = [] { const char *e = getenv("SR355_WGRAD_STREAM"); return e ? atoi(e) : 1; }();
+    SideStream *ss = side_knob ? side_stream() : nullptr;
+    std::unique_lock<std::mutex> side_lock;
+    if (ss) side_lock = std::unique_lock<std::mutex>(ss->in_use);
+    hipStream_t wstream = ss ? ss->stream[0] : stream;
+    // `after_main`: the side stream first waits for everything issued on the main stream so far
     auto wgrad = [&](size_t conv_idx, const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_off,
-                     int h, int w, float scale) -> int {
+                     int h, int w, float scale, bool after_main = true) -> int {
         const ConvSpec &sp = specs[conv_idx];
         float *dw = grads + goff[conv_idx];
+        if (ss && after_main &&
+            (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
+             check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))
+            return SR355_ERR_HIP;
         return launch_wgrad3x3(in, in_units, ups, dy, dy_units, dy_off, N, h, w, sp.cout, sp.cin, scale, 0, dw,
-                               dw + (size_t)sp.cout * sp.cin * 9, slabs, stream);
+                               dw + (size_t)sp.cout * sp.cin * 9, slabs, wstream);
     };
+    // side -> main hand-offs: mark(k) after the wgrads issued so far, await(k) before the main stream goes on
+    auto side_mark = [&](int k) -> int {
+        return ss ? check_hip(hipEventRecord(ss->side_mark[k], wstream), "hipEventRecord") : 0;
+    };
+    auto side_await = [&](int k) -> int {
+        return ss ? check_hip(hipStreamWaitEvent(stream, ss->side_mark[k], 0), "hipStreamWaitEvent") : 0;
+    };
+    // (every call ends with the main stream waiting for the side stream, so the slab workspace is free here)
     // data-gradient conv: forward kernel on transposed weights, zero bias
     auto dgrad = [&](const void *in, int in_units, int cin_units, size_t w_off, int cout, int h, int w,
                      const void *mask, int mask_units, int mask_off, const float *res1, float r1w, const float *res2,
@@ -1021,6 +1048,7 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
         return rc;
     }   // phase 0
     // RRDBs in reverse (:35-39, :18-24); the gradient-stack buffer alternates once per dense block
+    int blocks_done = 0;   // dense blocks of this call whose wgrads have been issued
     for (int b = nb - 1; b >= 0; --b) {
         const int phase = nb - b;
         if (phase < phase_begin || phase >= phase_end) continue;
@@ -1030,17 +1058,27 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
             const unsigned char *A = sb + sv.blk + (size_t)i * sv.blk_stride;   // forward activations of this block
             const size_t c1 = 1 + (size_t)i * 5;                                 // conv1 of this block in `specs`
             const float s5 = (r == 2) ? 0.04f : 0.2f;
-            // conv5: dY5 = s5 * (gradient held in GB[cur] units [0, nf))
-            if ((rc = wgrad(c1 + 4, A, bu, 0, GB[cur], bu, 0, H, W, s5))) return rc;
+            // the four growth convs' data gradients fill the stack; then its five weight gradients go to the side
+            // stream behind one hand-off (conv5: dY5 = s5 * the gradient held in GB[cur] units [0, nf))
             for (int j = 4; j >= 1; --j) {
                 const int in_units = (nf + (4 - j) * gc) / 8, out_off = in_units;
                 if ((rc = dgrad(GB[cur], bu, in_units, bp.rdb[(size_t)i * 5 + j], gc, H, W, A, bu,
                                 (nf + (j - 1) * gc) / 8, nullptr, 1.f, nullptr, 1.f, nullptr, GB[cur], bu, out_off,
                                 nullptr)))
                     return rc;
-                if ((rc = wgrad(c1 + (j - 1), A, bu, 0, GB[cur], bu, out_off, H, W, 1.f))) return rc;
+            }
+            if ((rc = wgrad(c1 + 4, A, bu, 0, GB[cur], bu, 0, H, W, s5, true))) return rc;
+            for (int j = 4; j >= 1; --j) {
+                const int out_off = (nf + (4 - j) * gc) / 8;
+                if ((rc = wgrad(c1 + (j - 1), A, bu, 0, GB[cur], bu, out_off, H, W, 1.f, false))) return rc;
             }
             const int nxt = cur ^ 1;
+            // the next write goes to GB[nxt] units [0, nf): the conv5 weight gradient of the dense block before
+            // this one reads them, and this block's own stack is rewritten one block later
+            const int par = blocks_done & 1;
+            if (blocks_done > 0 && side_await(par ^ 1)) return SR355_ERR_HIP;
+            if (side_mark(par)) return SR355_ERR_HIP;
+            ++blocks_done;
             if (r == 2)        // dX3 = 0.2 gR + conv
                 rc = dgrad(GB[cur], bu, bu, bp.rdb[(size_t)i * 5], nf, H, W, nullptr, 0, 0, gR, 0.2f, nullptr, 1.f, gT,
                            GB[nxt], bu, 0, nullptr);
@@ -1054,7 +1092,10 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
             cur = nxt;
         }
     }
-    if (phase_end < nb + 2) return SR355_OK;
+    if (phase_end < nb + 2) {   // join: the gradients of these phases are complete in stream order
+        if (side_mark(0) || side_await(0)) return SR355_ERR_HIP;
+        return SR355_OK;
+    }
     // conv_first (:56): gradient of fea = body path (gR) + global skip (gL1)
     {
         const size_t n_units8 = (size_t)N * H * W * nfu;
@@ -1068,7 +1109,9 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     if (grad_in_nchw)
         rc = dgrad(wb + bw.dfea, nfu, nfu, bp.first, cfg->in_channels, H, W, nullptr, 0, 0, nullptr, 1.f, nullptr, 1.f,
                    nullptr, nullptr, 0, 0, grad_in_nchw);
-    return rc;
+    if (rc) return rc;
+    if (side_mark(0) || side_await(0)) return SR355_ERR_HIP;   // join
+    return SR355_OK;
 }
 
 int sr355_generator_backward(const sr355_generator_cfg *cfg, const void *packed_bwd, size_t packed_bwd_bytes,
