@@ -107,7 +107,7 @@ def measure_kernels(net, N, H, W, forwards=3):
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -131,13 +131,13 @@ def roofline_from(rows):
         out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6,
                     "flop_per_launch": fl / cnt, "achieved": fl / sec / 1e12, "time_s": sec}
     dom = max(out, key=lambda s: out[s]["time_s"])
-    names = {"MB1": "conv3x3_ring<MB=1,NB=2,WAVES=4,R=3> (Cout<=32)", "MB2": "conv3x3_ring<MB=2,NB=2,WAVES=4,R=2> (Cout=64)"}
+    names = {"MB1": "conv3x3_fine<MB=1,NB=2,R=3> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2> (Cout=64)"}
     d = out[dom]
-    symbols = {"MB1": "conv3x3_ring<1, 2, 4, 3, 2>", "MB2": "conv3x3_ring<2, 2, 4, 2, 2>"}
+    symbols = {"MB1": "conv3x3_fine<1, 2, 3, 2>", "MB2": "conv3x3_fine<2, 2, 2, 2>"}
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r01c_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
+            "traffic_source": "profiles/r01e_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
                               "of this command with --streams 1)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"],

@@ -1,17 +1,18 @@
-// conv3x3 forward, persistent LDS-DMA ring variant (bf16 path, large images).
+// conv3x3 forward, ring kernel with a branch-free stage body (bf16 path, large images).
 //
-// Same arithmetic, operand maps and epilogue as conv3x3_mfma (conv3x3.hip); what changes is
-// how bytes reach the LDS and how the matrix pipe is kept fed:
-//   * persistent workgroups walk a list of (WAVES*NB)x32 tiles, XCD-contiguous, and the loads of the
-//     next tile's first stages are already in flight while a tile is being finished;
-//   * stages (16 input channels: haloed input tile + all taps of the weights) are written straight
-//     into LDS by `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write; padding pixels read
-//     beyond the buffer descriptor's range and arrive as zeros);
-//   * a ring of R stage slots keeps R-1 stages in flight behind a counted `s_waitcnt vmcnt(N)` and
-//     one raw `s_barrier` per stage;
-//   * the MFMA operands of tap column kx+1 are read from LDS while the MFMAs of column kx issue
-//     (explicit register double buffering of the fragments).
-// Replaces nn.Conv2d + cat + LeakyReLU + skips of /root/reference/esrgan/models/esrgan_model.py:18-24.
+// Same tiles, ring, operand maps and epilogue as conv3x3_ring (conv3x3_ring.hip); replaces nn.Conv2d + cat +
+// LeakyReLU + skips of /root/reference/esrgan/models/esrgan_model.py:18-24.  What changes is how one wave
+// keeps the matrix pipe busy on its own.  In conv3x3_ring the LDS fragment reads, the DMA issue and the MFMAs
+// of a stage run as separate phases and a wave alone on its SIMD keeps the pipe about half busy: fine while
+// two workgroups share the SIMD in the same phase, wasteful whenever the partner is in its prologue, at a
+// barrier or in its epilogue (the partner's gap could be filled, but is not).  Here
+//   * the DMA issue of a stage has no branches: every wave issues the same number of instructions per stage
+//     (a wave whose last slot does not exist sends an out-of-range load to a 1 KiB dummy area), the buffer
+//     descriptors are rebuilt from scalarised words so that no readfirstlane loop wraps the loads, and the
+//     issue cursor / next-tile set-up (which do branch) run after the MFMAs of the stage;
+//   * so the MFMAs of tap column kx, the LDS reads of column kx+1 and the DMA issue form one basic block, and
+//     `sched_group_barrier` interleaves them one MFMA at a time (an MFMA occupies the pipe for 32 cycles; an
+//     LDS read or a DMA issues in its shadow).
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
@@ -19,54 +20,56 @@
 
 namespace sr355 {
 
-// Timeline instrumentation (tools/trace_conv): with -DSR355_TRACE every workgroup stamps the 100 MHz wall
-// clock at fixed points of its life into 16 slots of the buffer this pointer names.
-unsigned long long *g_conv_trace = nullptr;
+extern unsigned long long *g_conv_trace;
 #ifdef SR355_TRACE
-#define SR355_STAMP(K)                                                                                \
+#define SR355_FSTAMP(K)                                                                               \
     if (a.trace && threadIdx.x == 0) a.trace[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (K)] = wall_clock64();
 #else
-#define SR355_STAMP(K)
+#define SR355_FSTAMP(K)
 #endif
 
+namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 
-namespace {
 constexpr int TWP = 34;          // tile width 32 + halo
 constexpr int RSU = 2;           // units per stage
 constexpr int OOB = 0x7fffff00;  // byte offset beyond any descriptor range -> DMA writes zeros
 
-template <int MB, int NB, int WAVES, int R>
-struct RingGeo {
+template <int MB, int NB, int R>
+struct FineGeo {
+    static constexpr int WAVES = 4;
     static constexpr int CO = MB * 32;
-    static constexpr int TH = WAVES * NB;                 // tile height
-    static constexpr int NPIX = (TH + 2) * TWP;           // haloed pixels
-    static constexpr int NIN = RSU * NPIX;                // input items (16 B each) per stage
-    static constexpr int NIN_I = (NIN + 63) / 64;         // wave-instructions for the input image
-    static constexpr int NWT = RSU * 9 * CO;              // weight items per stage (multiple of 64)
+    static constexpr int TH = WAVES * NB;
+    static constexpr int NPIX = (TH + 2) * TWP;
+    static constexpr int NIN = RSU * NPIX;
+    static constexpr int NIN_I = (NIN + 63) / 64;
+    static constexpr int NWT = RSU * 9 * CO;
     static constexpr int NWT_I = NWT / 64;
-    static constexpr int JTOT = NIN_I + NWT_I;            // wave-instructions per stage
-    static constexpr int KMAX = (JTOT + WAVES - 1) / WAVES;
-    static constexpr int KMIN = JTOT / WAVES;
-    static constexpr int W_OFF = NIN_I * 1024;            // weights follow the padded input image
+    static constexpr int JTOT = NIN_I + NWT_I;
+    static constexpr int KMAX = (JTOT + WAVES - 1) / WAVES;     // DMA instructions per wave and stage, all waves
+    static constexpr int W_OFF = NIN_I * 1024;
     static constexpr int STAGE_BYTES = JTOT * 1024;
     static constexpr int BIAS_OFF = R * STAGE_BYTES;
-    static constexpr int LDS_BYTES = BIAS_OFF + 256;
-    static constexpr int THREADS = WAVES * 64;
+    static constexpr int DUMMY_OFF = BIAS_OFF + 256;            // landing area of the padding loads
+    static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
+    static constexpr int N_READS = 3 * MB + NB + 2;             // LDS reads of one tap column
+    static constexpr int N_MFMA = 3 * MB * NB;                  // MFMAs of one tap column
     static_assert(NWT % 64 == 0, "weight image must be whole wave-instructions");
     static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
     static_assert(CO <= 64, "bias image is one 256-byte DMA");
+    static_assert((R - 2) * KMAX <= 63, "vmcnt field is 6 bits");
+    static_assert(2 * N_MFMA >= N_READS && N_MFMA >= KMAX, "not enough MFMAs to hide the reads / the DMA issue");
 };
 }  // namespace
 
-template <int MB, int NB, int WAVES, int R, int WPS>
-__global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a) {
-    typedef RingGeo<MB, NB, WAVES, R> G;
+template <int MB, int NB, int R, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
+    typedef FineGeo<MB, NB, R> G;
+    constexpr int WAVES = G::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    SR355_STAMP(0);
+    SR355_FSTAMP(0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,8 +84,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
     const int S = a.n_stages, n_real = a.n_real_stages;
     const int cb = blockIdx.y;
 
-    // Tile list of this workgroup.  Blocks b and b+8 share an XCD; remap so that the blocks of one
-    // XCD take consecutive tiles of every round (neighbouring tiles share halo rows in that L2).
+    // Blocks b and b+8 share an XCD: give the blocks of one XCD consecutive tiles of every round.
     const int n_tiles = a.N * a.tiles_y * a.tiles_x;
     const int nwg = gridDim.x;
     int first;
@@ -93,22 +95,30 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
     const int n_my = first < n_tiles ? (n_tiles - first + nwg - 1) / nwg : 0;
     const int total_g = n_my * S;
 
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned char *>(a.w) + (size_t)cb * G::CO * 16, 0, w_stage_stride * S, 0x00020000);
-    // bias -> LDS by one 4-byte-per-lane DMA (oldest operation of wave 0, so every later wait covers it)
-    if (wave == 0) {
+    // descriptors are kept as scalar words and rebuilt where they are used
+    const unsigned long long w_base = (unsigned long long)(a.w) + (size_t)cb * G::CO * 16;
+    const int w_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)w_base);
+    const int w_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(w_base >> 32));
+    const int w_len = __builtin_amdgcn_readfirstlane(w_stage_stride * S);
+    const int in_len = __builtin_amdgcn_readfirstlane(img_bytes);
+#define SR355_RSRC(LO, HI, LEN)                                                                       \
+    __builtin_amdgcn_make_buffer_rsrc(                                                                \
+        (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(HI) << 32) |           \
+                 (unsigned)__builtin_amdgcn_readfirstlane(LO)),                                       \
+        0, __builtin_amdgcn_readfirstlane(LEN), 0x00020000)
+    if (wave == 0) {   // bias: oldest operation of wave 0, retired by its first wait
         const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(a.bias) + cb * G::CO, 0, G::CO * 4, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void *)(smem + G::BIAS_OFF), 4, lane * 4, 0, 0, 0);
     }
 
-    // ---- issue side: per-lane source offsets of this wave's DMA instructions (j = k*WAVES + wave) ----
+    // per-lane source offsets of this wave's DMA instructions (j = k*WAVES + wave)
     int voff[G::KMAX];
 #pragma unroll
     for (int k = 0; k < G::KMAX; ++k) {
         const int j = k * WAVES + wave;
         voff[k] = OOB;
-        if (j >= G::NIN_I && j < G::JTOT) {   // weight items are tile invariant
+        if (j >= G::NIN_I && j < G::JTOT) {   // weight items do not depend on the tile
             const int jw = (j - G::NIN_I) * 64 + lane;
             const int u = jw / (9 * G::CO);
             const int rem = jw - u * 9 * G::CO;
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
             voff[k] = ((u * 9 + tap) * a.cout_pad + co) * 16;
         }
     }
-    __amdgpu_buffer_rsrc_t in_rsrc = w_rsrc;
+    int in_lo = w_lo, in_hi = w_hi;   // base of the image the issue cursor is in
     int it_tile = 0, it_stage = 0;
 
 #define SR355_TILE_SETUP(ORD)                                                                         \
@@ -127,8 +137,9 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
         const int tr_ = t_ / a.tiles_x;                                                               \
         const int tyi_ = tr_ % a.tiles_y;                                                             \
         const int n_ = tr_ / a.tiles_y;                                                               \
-        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in) + (size_t)n_ * img_bytes, \
-                                                    0, img_bytes, 0x00020000);                        \
+        const unsigned long long ib_ = (unsigned long long)(a.in) + (size_t)n_ * img_bytes;           \
+        in_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ib_);                                   \
+        in_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib_ >> 32));                           \
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                         \
             const int j = k * WAVES + wave;                                                           \
             if (j < G::NIN_I) {                                                                       \
@@ -145,40 +156,44 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
         }                                                                                             \
     }
 
-    // One stage of DMA into ring slot SLOT.  Past the end of the tile list the same instructions are
-    // issued with out-of-range sources (zeros into a free slot) so the vmcnt arithmetic stays uniform.
-#define SR355_ISSUE_STAGE(SLOT)                                                                       \
+    // One stage of DMA into ring slot SLOT, without a branch: instruction k of wave w is item j = k*WAVES + w;
+    // whether it is an activation item, a weight item or padding is decided by scalar selects.  Past the end of
+    // the tile list the same instructions go out with out-of-range sources (zeros into a free slot).
+#define SR355_ISSUE_DMA(SLOT)                                                                         \
     {                                                                                                 \
         const bool live_ = it_tile < n_my;                                                            \
         const int si_ = it_stage >= n_real ? it_stage - n_real : it_stage;                            \
-        const int soff_in_ = si_ * in_stage_stride;                                                   \
-        const int soff_w_ = it_stage * w_stage_stride;                                                \
-        unsigned char *dst_ = smem + (SLOT) * G::STAGE_BYTES + wave * 1024;                           \
+        const int soff_in_ = __builtin_amdgcn_readfirstlane(si_ * in_stage_stride);                   \
+        const int soff_w_ = __builtin_amdgcn_readfirstlane(it_stage * w_stage_stride);                \
+        const int dst0_ = (SLOT) * G::STAGE_BYTES + wave * 1024;                                      \
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                         \
             const int j = k * WAVES + wave;                                                           \
-            lds_void *l_ = (lds_void *)(dst_ + k * WAVES * 1024);                                     \
-            const int vo_ = live_ ? voff[k] : OOB;                                                    \
-            if (k * WAVES + WAVES - 1 < G::NIN_I) {                                                   \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l_, 16, vo_, soff_in_, 0, 0);       \
-            } else if (k * WAVES >= G::NIN_I && k * WAVES + WAVES - 1 < G::JTOT) {                    \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, l_, 16, vo_, soff_w_, 0, 0);         \
-            } else if (j < G::JTOT) {                                                                 \
-                if (j < G::NIN_I)                                                                     \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l_, 16, vo_, soff_in_, 0, 0);   \
-                else                                                                                  \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, l_, 16, vo_, soff_w_, 0, 0);     \
-            }                                                                                         \
+            const bool all_in_ = k * WAVES + WAVES - 1 < G::NIN_I;                                    \
+            const bool all_w_ = k * WAVES >= G::NIN_I && k * WAVES + WAVES - 1 < G::JTOT;             \
+            const bool is_in_ = all_in_ || (!all_w_ && j < G::NIN_I);                                 \
+            const bool exists_ = all_in_ || all_w_ || j < G::JTOT;                                    \
+            const int lo_ = is_in_ ? in_lo : w_lo, hi_ = is_in_ ? in_hi : w_hi;                       \
+            const int len_ = is_in_ ? in_len : w_len, so_ = is_in_ ? soff_in_ : soff_w_;              \
+            const int dst_ = exists_ ? dst0_ + k * WAVES * 1024 : G::DUMMY_OFF;                       \
+            const int vo_ = (live_ && exists_) ? voff[k] : OOB;                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16, vo_, \
+                                                     so_, 0, 0);                                      \
         }                                                                                             \
-        if (live_ && ++it_stage == S) {                                                               \
-            it_stage = 0;                                                                             \
-            if (++it_tile < n_my) SR355_TILE_SETUP(it_tile);                                          \
-        }                                                                                             \
+    }
+    // advance the issue cursor (and set the next tile up): branches, kept out of the MFMA blocks
+#define SR355_ISSUE_ADVANCE()                                                                         \
+    if (it_tile < n_my && ++it_stage == S) {                                                          \
+        it_stage = 0;                                                                                 \
+        if (++it_tile < n_my) SR355_TILE_SETUP(it_tile);                                              \
     }
 
     if (n_my > 0) SR355_TILE_SETUP(0);
 #pragma unroll
-    for (int g = 0; g < R - 1; ++g) SR355_ISSUE_STAGE(g);
-    SR355_STAMP(1);
+    for (int g = 0; g < R - 1; ++g) {
+        SR355_ISSUE_DMA(g);
+        SR355_ISSUE_ADVANCE();
+    }
+    SR355_FSTAMP(1);
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -210,36 +225,50 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
                 }                                                                                     \
             }                                                                                         \
     }
+    // MFMA = 0x008, VMEM read = 0x020, DS read = 0x100
+#define SR355_INTERLEAVE(N_DS, N_VMEM, SYNC)                                                          \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < G::N_MFMA; ++i_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);                                     \
+            if (i_ < (N_DS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);                    \
+            if (i_ + G::N_MFMA < (N_DS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);        \
+            if (i_ < (N_VMEM)) __builtin_amdgcn_sched_group_barrier(0x020, 1, SYNC);                  \
+        }                                                                                             \
+    }
 
     int slot = 0, issue_slot = R - 1, ct_stage = 0, ct_tile = 0;
     for (int g = 0; g < total_g; ++g) {
-        // stage g has landed for this wave when at most (R-2) younger stages are outstanding;
-        // after the barrier it has landed for every wave, and slot (g-1)%R is free to refill.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G::KMIN) : "memory");
+        // stage g has landed for this wave when at most (R-2) younger stages are outstanding; after the
+        // barrier it has landed for every wave, and slot (g-1)%R is free to refill
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G::KMAX) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (g == 0) SR355_STAMP(2);
+        if (g == 0) SR355_FSTAMP(2);
         const unsigned char *buf = smem + slot * G::STAGE_BYTES;
         const unsigned char *pin = buf + lane_in;
         const unsigned char *pw = buf + lane_w;
         bf16x8 wfA[3][MB], xfA[NB + 2], wfB[3][MB], xfB[NB + 2];
         SR355_LOAD_FRAGS(wfA, xfA, 0);
-        SR355_ISSUE_STAGE(issue_slot);
-        issue_slot = issue_slot + 1 == R ? 0 : issue_slot + 1;
         __builtin_amdgcn_sched_barrier(0);
+        // column 0: its MFMAs, the reads of column 1 and this stage's DMA issue, one of each at a time
+        SR355_ISSUE_DMA(issue_slot);
         SR355_LOAD_FRAGS(wfB, xfB, 1);
-        __builtin_amdgcn_sched_barrier(0);
         SR355_MMA_FRAGS(wfA, xfA);
+        SR355_INTERLEAVE(G::N_READS, G::KMAX, 0);
         __builtin_amdgcn_sched_barrier(0);
+        // column 1 under the reads of column 2
         SR355_LOAD_FRAGS(wfA, xfA, 2);
-        __builtin_amdgcn_sched_barrier(0);
         SR355_MMA_FRAGS(wfB, xfB);
+        SR355_INTERLEAVE(G::N_READS, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         SR355_MMA_FRAGS(wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_slot = issue_slot + 1 == R ? 0 : issue_slot + 1;
+        SR355_ISSUE_ADVANCE();
         slot = slot + 1 == R ? 0 : slot + 1;
 
         if (++ct_stage == S) {
             // ---- epilogue of tile ct_tile ----
-            if (ct_tile < 6) SR355_STAMP(3 + 2 * ct_tile);
+            if (ct_tile < 6) SR355_FSTAMP(3 + 2 * ct_tile);
             const int t = first + ct_tile * nwg;
             const int tx_i = t % a.tiles_x;
             const int tr = t / a.tiles_x;
@@ -267,27 +296,29 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
                 }
             }
             ct_stage = 0;
-            if (ct_tile < 6) SR355_STAMP(4 + 2 * ct_tile);
+            if (ct_tile < 6) SR355_FSTAMP(4 + 2 * ct_tile);
             ++ct_tile;
         }
     }
     // drain the DMA still in flight (dummy stages) before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SR355_STAMP(15);
+    SR355_FSTAMP(15);
+#undef SR355_RSRC
 #undef SR355_TILE_SETUP
-#undef SR355_ISSUE_STAGE
+#undef SR355_ISSUE_DMA
+#undef SR355_ISSUE_ADVANCE
 #undef SR355_LOAD_FRAGS
 #undef SR355_MMA_FRAGS
+#undef SR355_INTERLEAVE
 }
 
-// WPS = waves per SIMD the register budget is sized for (workgroups per CU = WPS * 4 / WAVES).
-template <int MB, int NB, int WAVES, int R, int WPS = 2>
-static int launch_ring_inst(const ConvArgs &a0, hipStream_t stream) {
-    typedef RingGeo<MB, NB, WAVES, R> G;
+template <int MB, int NB, int R, int WPS = 2>
+static int launch_fine_inst(const ConvArgs &a0, hipStream_t stream) {
+    typedef FineGeo<MB, NB, R> G;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
-    auto kern = conv3x3_ring<MB, NB, WAVES, R, WPS>;
+    auto kern = conv3x3_fine<MB, NB, R, WPS>;
     static bool attr_done[64] = {};
     static int n_cu[64] = {};
     int dev = 0;
@@ -307,47 +338,23 @@ static int launch_ring_inst(const ConvArgs &a0, hipStream_t stream) {
     }
     const long long n_tiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) {
-        set_error("conv3x3 ring: %lld tiles is out of range", n_tiles);
+        set_error("conv3x3 fine: %lld tiles is out of range", n_tiles);
         return SR355_ERR_INVALID;
     }
     int wg_per_cu = (160 * 1024) / G::LDS_BYTES;
-    const int by_waves = WPS * 4 / WAVES;   // register budget
-    if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+    if (wg_per_cu > WPS) wg_per_cu = WPS;
     if (wg_per_cu < 1) wg_per_cu = 1;
     const long long slots = (long long)n_cu[dev] * wg_per_cu;
     dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots), a.cout_pad / G::CO, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, stream, a);
-    return check_hip(hipGetLastError(), "conv3x3 ring launch");
+    hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, stream, a);
+    return check_hip(hipGetLastError(), "conv3x3 fine launch");
 }
 
-// Ring kernel entry: bf16 only, cin_units even, cout_pad 32 or 64.
-int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipStream_t stream) {
+// Entry: bf16 only, cin_units even, cout_pad 32 or 64; `a` carries n_stages / n_real_stages / debug.
+int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     ConvArgs b = a;
-    b.n_real_stages = cin_units / 2;
-    b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
-    static const int dbg = [] { const char *e = getenv("SR355_DEBUG"); return e ? atoi(e) : 0; }();
-    static const int var = [] { const char *e = getenv("SR355_VARIANT"); return e ? atoi(e) : 9; }();
-    b.debug = dbg;
     b.trace = g_conv_trace;
-    const bool wide = (a.cout_pad % 64) == 0;
-    if (var == 9) return launch_conv3x3_fine(b, stream);
-    if (var == 1) {   // 4 waves x 4 rows, two workgroups per CU, one stage in flight each
-        return wide ? launch_ring_inst<2, 4, 4, 2>(b, stream) : launch_ring_inst<1, 4, 4, 2>(b, stream);
-    }
-    if (var == 2) {   // as 1, but 8-row tiles for the 64-channel convs (accumulators fit beside the prefetch)
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 4, 4, 2>(b, stream);
-    }
-    if (var == 3) {
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 2>(b, stream);
-    }
-    if (var == 4) {   // three workgroups per CU for the 32-channel convs
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 2, 3>(b, stream);
-    }
-    if (var == 5) {   // two stages in flight, two workgroups per CU, 32-channel convs
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 3>(b, stream);
-    }
-    // var == 0: one 8-wave workgroup per CU with a deep ring
-    return wide ? launch_ring_inst<2, 2, 8, 4>(b, stream) : launch_ring_inst<1, 2, 8, 5>(b, stream);
+    return (a.cout_pad % 64) == 0 ? launch_fine_inst<2, 2, 2>(b, stream) : launch_fine_inst<1, 2, 3>(b, stream);
 }
 
 }  // namespace sr355

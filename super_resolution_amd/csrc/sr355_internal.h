@@ -48,6 +48,9 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
 // Persistent LDS-DMA ring variant (bf16, large images); same contract as launch_conv3x3.
 int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipStream_t stream);
 
+// Ring kernel with a branch-free, MFMA-interleaved stage body; n_stages, n_real_stages and debug must be set.
+int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream);
+
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
                            int dst_units, int split, hipStream_t stream);
 int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C,

@@ -30,16 +30,25 @@ typedef __attribute__((ext_vector_type(16))) float tf32x16;
 
 // Pure matrix-pipe loop: NACC independent accumulators per wave, no memory traffic.
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, unsigned long long *clk) {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, unsigned long long *clk, int random_data) {
     tf32x16 acc[NACC];
     for (int i = 0; i < NACC; ++i)
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    tbf16x8 x, y;
-    for (int e = 0; e < 8; ++e) x[e] = (__bf16)(float)(threadIdx.x & 7), y[e] = (__bf16)1.0f;
+    // NACC different operand pairs: constants, or pseudo-random values in [-1, 1) (data toggling costs power)
+    tbf16x8 x[NACC], y[NACC];
+    unsigned rs = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = 0; i < NACC; ++i)
+        for (int e = 0; e < 8; ++e) {
+            rs = rs * 1664525u + 1013904223u;
+            const float a = random_data ? ((rs >> 8) & 0xffff) / 32768.f - 1.f : (float)(threadIdx.x & 7);
+            rs = rs * 1664525u + 1013904223u;
+            const float b = random_data ? ((rs >> 8) & 0xffff) / 32768.f - 1.f : 1.f;
+            x[i][e] = (__bf16)a, y[i][e] = (__bf16)b;
+        }
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[i], acc[i], 0, 0, 0);
     }
     float s = 0.f;
     for (int i = 0; i < NACC; ++i)
@@ -56,21 +65,22 @@ static int mfma_peak() {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
+    for (int random_data = 0; random_data <= 1; ++random_data)
     for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu)
-        for (int iters : {2000, 20000}) {
+        for (int iters : {2000, 20000, 200000}) {
             const int grid = 256 * wg_per_cu;
-            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk);
+            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk, random_data);
             (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk);
+            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk, random_data);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms = 0;
             (void)hipEventElapsedTime(&ms, e0, e1);
             (void)hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
             const double flop = (double)grid * 4 * iters * 4 * 32768.0;
-            printf("mfma peak: %d WG/CU x 4 waves, %d iters x 4 acc: %.1f us, %.0f TFLOP/s; clock64 %llu ticks per %llu x10ns -> %.0f MHz; %.1f clock64 ticks per MFMA per wave\n",
-                   wg_per_cu, iters, ms * 1e3, flop / (ms * 1e-3) / 1e12, h[0], h[1], h[0] / (h[1] * 0.01),
+            printf("mfma peak (%s operands): %d WG/CU x 4 waves, %d iters x 4 acc: %.1f us, %.0f TFLOP/s; clock64 %llu ticks per %llu x10ns -> %.0f MHz; %.1f clock64 ticks per MFMA per wave\n",
+                   random_data ? "random" : "constant", wg_per_cu, iters, ms * 1e3, flop / (ms * 1e-3) / 1e12, h[0], h[1], h[0] / (h[1] * 0.01),
                    (double)h[0] / (iters * 4.0));
         }
     return 0;
