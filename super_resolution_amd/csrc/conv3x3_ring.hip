@@ -330,24 +330,10 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
     b.debug = dbg;
     b.trace = g_conv_trace;
     const bool wide = (a.cout_pad % 64) == 0;
-    if (var == 9) return launch_conv3x3_fine(b, stream);
-    if (var == 1) {   // 4 waves x 4 rows, two workgroups per CU, one stage in flight each
-        return wide ? launch_ring_inst<2, 4, 4, 2>(b, stream) : launch_ring_inst<1, 4, 4, 2>(b, stream);
-    }
-    if (var == 2) {   // as 1, but 8-row tiles for the 64-channel convs (accumulators fit beside the prefetch)
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 4, 4, 2>(b, stream);
-    }
-    if (var == 3) {
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 2>(b, stream);
-    }
-    if (var == 4) {   // three workgroups per CU for the 32-channel convs
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 2, 3>(b, stream);
-    }
-    if (var == 5) {   // two stages in flight, two workgroups per CU, 32-channel convs
-        return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 3>(b, stream);
-    }
-    // var == 0: one 8-wave workgroup per CU with a deep ring
-    return wide ? launch_ring_inst<2, 2, 8, 4>(b, stream) : launch_ring_inst<1, 2, 8, 5>(b, stream);
+    // 9 (default): the branch-free, MFMA-interleaved stage body of conv3x3_fine.hip; 5: this file's phase-ordered
+    // body (two workgroups per CU; one stage in flight for the 64-channel convs, two for the 32-channel ones)
+    if (var != 5) return launch_conv3x3_fine(b, stream);
+    return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 3>(b, stream);
 }
 
 }  // namespace sr355
