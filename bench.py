@@ -379,14 +379,36 @@ def main():
             line["kernel_shapes"] = per_shape
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W)
+    hung = False
     if not args.no_train:
         del out
-        try:
-            line["train"] = train_rate(dev, world, dist, graph=args.train_graph)
-        except Exception as exc:      # the headline number above stands on its own
-            line["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1:
+            try:
+                line["train"] = train_rate(dev, world, dist, graph=args.train_graph)
+            except Exception as exc:      # the headline number above stands on its own
+                line["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+        else:
+            # collectives inside: a rank that fails or stalls must not take the headline line with it, so the
+            # extras run on a worker thread with a deadline
+            import threading
+            box = {}
+
+            def work():
+                try:
+                    torch.cuda.set_device(dev)        # the current device is per thread
+                    box["train"] = train_rate(dev, world, dist)
+                except Exception as exc:
+                    box["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(timeout=240.0)
+            hung = th.is_alive()
+            line["train"] = {"error": "training extras did not finish within 240 s"} if hung else box["train"]
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if hung:
+        os._exit(0)        # a stalled collective cannot be cancelled; the line is out
     if dist is not None:
         dist.destroy_process_group()
 
