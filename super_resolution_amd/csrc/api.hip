@@ -857,6 +857,8 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     upd(nf, nf, N, 2 * H, 2 * W);
     upd(nf, nf, N, 4 * H, 4 * W);
     upd(c.out_channels, nf, N, 4 * H, 4 * W);
+    const size_t block_slabs = wgrad_block_workspace_bytes(nf, gc, N, H, W);   // a dense block's five at once
+    if (block_slabs > slab) slab = block_slabs;
     b.slabs = take(slab);
     b.total = off;
     return b;
@@ -1067,10 +1069,16 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                                 nullptr)))
                     return rc;
             }
-            if ((rc = wgrad(c1 + 4, A, bu, 0, GB[cur], bu, 0, H, W, s5, true))) return rc;
-            for (int j = 4; j >= 1; --j) {
-                const int out_off = (nf + (4 - j) * gc) / 8;
-                if ((rc = wgrad(c1 + (j - 1), A, bu, 0, GB[cur], bu, out_off, H, W, 1.f, false))) return rc;
+            {
+                float *dw[5], *db[5];
+                for (int k = 0; k < 5; ++k) {
+                    dw[k] = grads + goff[c1 + k];
+                    db[k] = dw[k] + (size_t)specs[c1 + k].cout * specs[c1 + k].cin * 9;
+                }
+                if (ss && (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
+                           check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))
+                    return SR355_ERR_HIP;
+                if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
             }
             const int nxt = cur ^ 1;
             // the next write goes to GB[nxt] units [0, nf): the conv5 weight gradient of the dense block before

@@ -13,6 +13,8 @@
 // * partial weight gradients of different pixel ranges go to per-workgroup slabs (plain stores) and
 //   a second kernel sums them in a fixed order: deterministic, no float atomics;
 // * 2x2 sum pooling: the adjoint of the nearest x2 upsample fused in front of upconv1/upconv2.
+#include <string.h>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -148,6 +150,11 @@ struct WgradArgs {
     int in_units, ups;         // input geometry (ups: input at half resolution, nearest x2)
     int dy_units, dy_unit_off;
     int tiles_x, tiles_y;
+    // batched launch (blockIdx.z = conv of a dense block sharing `in` and `dy`): per-conv channel chunks,
+    // workgroups per chunk, position of its gradient in dy and of its slabs; n_batch = 0: single conv
+    int n_batch;
+    int z_chunks[4], z_groups[4], z_dy_unit_off[4];
+    long long z_slab_off[4], z_bias_off[4];   // in floats from `slabs`; bias < 0: none
 };
 
 namespace {
@@ -182,19 +189,34 @@ __device__ __forceinline__ bf16x8 read_tr_operand(const unsigned char *p) {
 }
 
 template <int MB>
-__device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a) {
+__device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     typedef WGeo<MB> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = ky
     const int chunk = blockIdx.y;
+    // view of the arguments for this conv of a batched launch
+    struct {
+        const unsigned char *in, *dy;
+        float *slabs, *bias_slabs;
+        int N, H, W, in_units, ups, dy_units, dy_unit_off, tiles_x, tiles_y;
+    } a = {a0.in, a0.dy, a0.slabs, a0.bias_slabs, a0.N, a0.H, a0.W, a0.in_units, a0.ups, a0.dy_units, a0.dy_unit_off,
+           a0.tiles_x, a0.tiles_y};
+    int nwg = gridDim.x;
+    if (a0.n_batch > 0) {
+        const int z = blockIdx.z;
+        nwg = a0.z_groups[z];
+        if (chunk >= a0.z_chunks[z] || (int)blockIdx.x >= nwg) return;   // whole workgroup, before any barrier
+        a.dy_unit_off = a0.z_dy_unit_off[z];
+        a.bias_slabs = a0.z_bias_off[z] >= 0 ? a0.slabs + a0.z_bias_off[z] : nullptr;
+        a.slabs = a0.slabs + a0.z_slab_off[z];
+    }
     const int H = a.H, W = a.W;
     const int Win = W >> a.ups;
     const int in_img_bytes = (H >> a.ups) * a.in_units * Win * 16;
     const int dy_img_bytes = H * a.dy_units * W * 16;
     const int n_tiles = a.N * a.tiles_y * a.tiles_x;
-    const int nwg = gridDim.x;
 
     int voff[G::KMAX];
     __amdgpu_buffer_rsrc_t in_rsrc, dy_rsrc;
@@ -373,6 +395,40 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__re
     }
 }
 
+// The same reduction for up to five convs in one launch (blockIdx.y = conv).
+struct WgradReduceJob {
+    const float *slabs, *bias_slabs;
+    float *dw, *db;
+    int cout, cin, CO, G;
+    float scale;
+};
+struct WgradReduceTable {
+    WgradReduceJob j[5];
+};
+__global__ void wgrad_reduce_batch_kernel(const WgradReduceTable t, int accumulate) {
+    const WgradReduceJob &j = t.j[blockIdx.y];
+    const int n_w = 9 * j.cout * j.cin;
+    const int total = n_w + (j.db ? j.cout : 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i >= n_w) {
+            const int co = i - n_w;
+            float sum = 0.f;
+            for (int gidx = 0; gidx < j.G; ++gidx) sum += j.bias_slabs[(size_t)gidx * j.CO + co];
+            j.db[co] = accumulate ? j.db[co] + j.scale * sum : j.scale * sum;
+            continue;
+        }
+        const int ci = i % j.cin;
+        const int tt = i / j.cin;
+        const int co = tt % j.cout;
+        const int tap = tt / j.cout;
+        const float *s = j.slabs + ((size_t)(ci >> 5) * j.G * 9 + tap) * j.CO * 32 + co * 32 + (ci & 31);
+        float sum = 0.f;
+        for (int gidx = 0; gidx < j.G; ++gidx) sum += s[(size_t)gidx * 9 * j.CO * 32];
+        float *d = j.dw + ((size_t)co * j.cin + ci) * 9 + tap;
+        *d = accumulate ? *d + j.scale * sum : j.scale * sum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 static unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
@@ -440,6 +496,90 @@ size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
     return ((size_t)chunks * G * 9 * 32 + G) * cout_pad_for(cout) * sizeof(float);
 }
 
+static int wgrad_set_attr(int mbi) {
+    static bool attr_done[2][64] = {};
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[mbi][dev]) {
+        hipError_t e = mbi ? hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb2),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<2>::LDS_BYTES)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb1),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<1>::LDS_BYTES);
+        if (check_hip(e, "hipFuncSetAttribute")) return SR355_ERR_HIP;
+        attr_done[mbi][dev] = true;
+    }
+    return SR355_OK;
+}
+
+size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
+    size_t total = 0;
+    for (int k = 0; k < 5; ++k) total += (wgrad_workspace_bytes(k < 4 ? gc : nf, nf + k * gc, N, H, W) + 255) & ~(size_t)255;
+    return total;
+}
+
+// The five weight / bias gradients of one dense block (esrgan_model.py:18-24) in three launches: conv1..conv4
+// (growth convs, gc <= 32 outputs each, blockIdx.z = conv), conv5 (nf <= 64 outputs), one reduction.
+// `act` = the block's forward buffer, `stack` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
+// dw[k] / db[k] receive conv(k+1)'s gradients; conv5's is scaled by s5.
+int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
+                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream) {
+    if (cout_pad_for(gc) != 32 || cout_pad_for(nf) > 64 || ((nf | gc) & 7)) {
+        set_error("wgrad3x3 block: nf=%d gc=%d not supported", nf, gc);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const unsigned char *)act;
+    a.dy = (const unsigned char *)stack;
+    a.slabs = slabs;
+    a.N = N, a.H = H, a.W = W;
+    a.in_units = units, a.ups = 0, a.dy_units = units;
+    a.tiles_x = (W + 31) / 32;
+    a.tiles_y = (H + WTH - 1) / WTH;
+    WgradReduceTable rt;
+    size_t off = 0;   // floats
+    int max_chunks = 0, max_g = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int cin = nf + k * gc, cout = k < 4 ? gc : nf, co_pad = cout_pad_for(cout);
+        int chunks, G;
+        wgrad_geometry(cin, N, H, W, &chunks, &G);
+        const int dy_off = k < 4 ? (nf + (3 - k) * gc) / 8 : 0;   // stack order: dOut, dY4, dY3, dY2, dY1
+        const size_t bias_off = off + (size_t)chunks * G * 9 * co_pad * 32;
+        rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[k], db[k], cout, cin, co_pad, G, k < 4 ? 1.f : s5};
+        if (k < 4) {
+            a.z_chunks[k] = chunks, a.z_groups[k] = G, a.z_dy_unit_off[k] = dy_off;
+            a.z_slab_off[k] = (long long)off, a.z_bias_off[k] = (long long)bias_off;
+            if (chunks > max_chunks) max_chunks = chunks;
+            if (G > max_g) max_g = G;
+        }
+        off += ((wgrad_workspace_bytes(cout, cin, N, H, W) + 255) & ~(size_t)255) / sizeof(float);
+    }
+    int rc;
+    if ((rc = wgrad_set_attr(0)) || (rc = wgrad_set_attr(1))) return rc;
+    a.n_batch = 4;
+    hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
+    if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
+    // conv5 on its own (64 output channels take the two-block instantiation)
+    WgradArgs a5 = a;
+    a5.n_batch = 0;
+    a5.dy_unit_off = 0;
+    a5.slabs = const_cast<float *>(rt.j[4].slabs);
+    a5.bias_slabs = const_cast<float *>(rt.j[4].bias_slabs);
+    {
+        int chunks, G;
+        wgrad_geometry(nf + 4 * gc, N, H, W, &chunks, &G);
+        if (cout_pad_for(nf) == 64)
+            hipLaunchKernelGGL(wgrad3x3_kernel_mb2, dim3(G, chunks, 1), dim3(192), WGeo<2>::LDS_BYTES, stream, a5);
+        else
+            hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(G, chunks, 1), dim3(192), WGeo<1>::LDS_BYTES, stream, a5);
+        if (check_hip(hipGetLastError(), "wgrad3x3 conv5 launch")) return SR355_ERR_HIP;
+    }
+    const size_t biggest = (size_t)9 * nf * (nf + 4 * gc) + nf;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(grid_for(biggest), 5), dim3(256), 0, stream, rt, 0);
+    return check_hip(hipGetLastError(), "wgrad reduce batch launch");
+}
+
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream) {
@@ -451,6 +591,7 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     int chunks, G;
     wgrad_geometry(cin, N, H, W, &chunks, &G);
     WgradArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = (const unsigned char *)in;
     a.dy = (const unsigned char *)dy;
     a.slabs = slabs;

@@ -83,6 +83,10 @@ int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const 
                    int mask_unit_off, float mask_slope, float *out_f32, void *out_act, int out_units, int out_unit_off,
                    hipStream_t stream);
 size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
+// All five weight / bias gradients of a dense block in three launches (see backward.hip).
+size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W);
+int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
+                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream);
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream);

@@ -118,10 +118,10 @@ class DistributedGenerator(nn.Module):
                 dist.broadcast(p.data, src=src, group=self.group)
 
     def forward(self, x: Tensor) -> Tensor:
-        from .esrgan_model import _GeneratorFunction
+        from .esrgan_model import _GeneratorFunction, _graph_params
         m = self.module
         xin = x.float().contiguous()
         params = [p for c in m.conv_modules() for p in (c.weight, c.bias)]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _GeneratorFunction.apply(xin, m, self, *params)
+            return _GeneratorFunction.apply(xin, m, self, *_graph_params(m, params))
         return m(x)

@@ -134,13 +134,19 @@ class GeneratorRRDB(nn.Module):
     fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path).
     ``hr_split`` (bf16 only) carries the bf16 rounding residue of the weights of the four
     HR-side convs, and of the input and weights of conv_first, as extra MFMA terms; their rounding
-    otherwise dominates the output error (50.0 dB -> 53.9 dB PSNR against fp32 at +8 % MFMA work)."""
+    otherwise dominates the output error (50.0 dB -> 53.9 dB PSNR against fp32 at +8 % MFMA work).
+    ``direct_grads``: the backward pass writes (or adds) every parameter's ``.grad`` itself, as slices of one
+    flat buffer, instead of handing 702 gradients to autograd's per-parameter accumulation: the same ``.grad``
+    fields after ``loss.backward()`` (optimizers, ``GradScaler``, gradient accumulation see no difference) at a
+    third of the host time of a small-patch step.  Pass ``False`` to keep per-parameter autograd edges
+    (``torch.autograd.grad(loss, netG.parameters())``, tensor hooks on the parameters)."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, num_features: int = 64,
                  num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16",
-                 hr_split: bool = True):
+                 hr_split: bool = True, direct_grads: bool = True):
         super().__init__()
         self.hr_split = bool(hr_split)
+        self.direct_grads = bool(direct_grads)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -201,10 +207,21 @@ class GeneratorRRDB(nn.Module):
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
             if _PRECISIONS[self.precision] != DTYPE_BF16:
                 raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
-            return _GeneratorFunction.apply(xin, self, None, *params)
+            return _GeneratorFunction.apply(xin, self, None, *_graph_params(self, params))
         N, _c, H, W = xin.shape
         return ops.generator_forward(xin.detach(), self.packed_parameters(), self.workspace(N, H, W, xin.device),
                                      self.cfg())
+
+
+def _graph_params(module: "GeneratorRRDB", params: List[Tensor]) -> List[Tensor]:
+    """The parameters the autograd node takes as inputs: all of them, or with ``direct_grads`` one trainable
+    parameter that merely ties the node into the graph (the backward then fills ``.grad`` itself)."""
+    if not module.direct_grads:
+        return params
+    for p in params:
+        if p.requires_grad:
+            return [p]
+    return []
 
 
 class _GeneratorFunction(torch.autograd.Function):
@@ -221,7 +238,8 @@ class _GeneratorFunction(torch.autograd.Function):
         out = ops.generator_forward_train(x.detach(), module.packed_parameters(), saved, ws, cfg)
         ctx.module, ctx.saved, ctx.lr_shape, ctx.reducer = module, saved, (N, H, W), reducer
         ctx.need_x = x.requires_grad
-        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.n_graph_params = len(params)
+        ctx.direct = module.direct_grads
         return out
 
     @staticmethod
@@ -242,14 +260,28 @@ class _GeneratorFunction(torch.autograd.Function):
             reduce_in_buckets(flat, ctx.reducer.buckets,
                               lambda pb, pe: ops.generator_backward_range(gout, packed_bwd, ctx.saved, ws, flat, gin, cfg,
                                                                           H, W, pb, pe), ctx.reducer.group)
-        grads, off = [], 0
-        for shape in ctx.param_shapes:
-            n = 1
-            for d in shape:
-                n *= d
-            grads.append(flat[off:off + n].view(shape))
-            off += n
-        return (gin if ctx.need_x else None, None, None, *grads)
+        params = [p for c in module.conv_modules() for p in (c.weight, c.bias)]
+        # one split for all 702 slices, then a reshape of the 4-d ones (biases are 1-d already)
+        views = list(flat.split_with_sizes([p.numel() for p in params]))
+        for i in range(0, len(views), 2):
+            views[i] = views[i].view(params[i].shape)
+        gx = gin if ctx.need_x else None
+        if not ctx.direct:
+            return (gx, None, None, *views)
+        # what autograd's accumulation would do, parameter by parameter: the first gradient becomes .grad
+        # (a slice of the flat buffer), later ones are added to it
+        have_p, have_v = [], []
+        for p, v in zip(params, views):
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = v
+            else:
+                have_p.append(p.grad)
+                have_v.append(v)
+        if have_p:
+            torch._foreach_add_(have_p, have_v)
+        return (gx, None, None, *([None] * ctx.n_graph_params))
 
 
 # RRDBNet is the name BasicSR-derived code uses for the same network.

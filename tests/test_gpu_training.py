@@ -144,6 +144,29 @@ def test_grad_scaler_call_site_and_accumulation():
         assert rel_l2(p.grad / 131072.0, base[k]) < 1e-2, k
 
 
+def test_direct_and_per_parameter_gradient_delivery_agree():
+    """The module writes .grad itself by default; direct_grads=False hands every gradient to autograd.  Same
+    kernels, so the same bits; frozen parameters get no .grad either way; torch.autograd.grad needs the
+    per-parameter edges."""
+    sd = O.make_generator_state(43, num_blocks=1)
+    x = torch.rand(2, 3, 8, 12, generator=torch.Generator().manual_seed(44)).to(DEV)
+    grads = []
+    for direct in (True, False):
+        net = S.GeneratorRRDB(num_blocks=1, direct_grads=direct).to(DEV)
+        net.load_state_dict(sd)
+        net.train()
+        net.HR_conv.weight.requires_grad_(False)
+        xin = x.clone().requires_grad_(True)
+        net(xin).square().mean().backward()
+        assert net.HR_conv.weight.grad is None
+        grads.append({k: p.grad for k, p in net.named_parameters() if p.grad is not None} | {"x": xin.grad})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) == 2 * 21 - 1 + 1
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+    gw, = torch.autograd.grad(net(x).square().mean(), [net.conv_last.weight])
+    assert torch.equal(gw, grads[1]["conv_last.weight"])
+
+
 def test_backward_full_depth_small_patch(golden):
     g = golden("g4_gen23.npz")
     sd = O.center_outputs(O.make_generator_state(int(g["seed"])), float(g["bias_shift"]))
