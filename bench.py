@@ -131,9 +131,9 @@ def roofline_from(rows):
         out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6,
                     "flop_per_launch": fl / cnt, "achieved": fl / sec / 1e12, "time_s": sec}
     dom = max(out, key=lambda s: out[s]["time_s"])
-    names = {"MB1": "conv3x3_fine<MB=1,NB=2,R=3> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2> (Cout=64)"}
+    names = {"MB1": "conv3x3_fine<MB=1,NB=4,R=2> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2> (Cout=64)"}
     d = out[dom]
-    symbols = {"MB1": "conv3x3_fine<1, 2, 3, 2>", "MB2": "conv3x3_fine<2, 2, 2, 2>"}
+    symbols = {"MB1": "conv3x3_fine<1, 4, 2, 2>", "MB2": "conv3x3_fine<2, 2, 2, 2>"}
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),

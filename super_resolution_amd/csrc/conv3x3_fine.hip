@@ -354,7 +354,25 @@ static int launch_fine_inst(const ConvArgs &a0, hipStream_t stream) {
 int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     ConvArgs b = a;
     b.trace = g_conv_trace;
-    return (a.cout_pad % 64) == 0 ? launch_fine_inst<2, 2, 2>(b, stream) : launch_fine_inst<1, 2, 3>(b, stream);
+    if ((a.cout_pad % 64) == 0) return launch_fine_inst<2, 2, 2>(b, stream);
+    // 32 output channels: a wave's MFMA run per stage is short, and the barrier plus the first fragment reads of
+    // every stage are exposed; 16-row tiles double the run (and halve the weight traffic per pixel) wherever they
+    // still give every CU a tile
+    static int cu_of[64] = {};
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!cu_of[dev]) {
+        int n = 0;
+        if (check_hip(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute"))
+            return SR355_ERR_HIP;
+        cu_of[dev] = n > 0 ? n : 256;
+    }
+    const int cu = cu_of[dev];
+    const long long tiles16 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
+    static const int force_nb = [] { const char *e = getenv("SR355_NARROW_NB"); return e ? atoi(e) : 0; }();
+    if (force_nb == 4 || (force_nb == 0 && tiles16 >= cu)) return launch_fine_inst<1, 4, 2>(b, stream);
+    return launch_fine_inst<1, 2, 3>(b, stream);
 }
 
 }  // namespace sr355
