@@ -24,8 +24,16 @@ extern unsigned long long *g_conv_trace;
 #ifdef SR355_TRACE
 #define SR355_FSTAMP(K)                                                                               \
     if (a.trace && threadIdx.x == 0) a.trace[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (K)] = wall_clock64();
+// in-stage stamps of wave 0 of every workgroup, taken in steady state (global stage 3): shader-clock ticks
+#define SR355_SSTAMP(K)                                                                               \
+    if (a.trace && g == 3) {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        st_[K] = __builtin_readcyclecounter();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
 #else
 #define SR355_FSTAMP(K)
+#define SR355_SSTAMP(K)
 #endif
 
 namespace {
@@ -237,11 +245,17 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     }
 
     int slot = 0, issue_slot = R - 1, ct_stage = 0, ct_tile = 0;
+#ifdef SR355_TRACE
+    unsigned long long st_[8] = {};
+#endif
     for (int g = 0; g < total_g; ++g) {
+        SR355_SSTAMP(0);
         // stage g has landed for this wave when at most (R-2) younger stages are outstanding; after the
         // barrier it has landed for every wave, and slot (g-1)%R is free to refill
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * G::KMAX) : "memory");
+        SR355_SSTAMP(1);
         __builtin_amdgcn_s_barrier();
+        SR355_SSTAMP(2);
         if (g == 0) SR355_FSTAMP(2);
         const unsigned char *buf = smem + slot * G::STAGE_BYTES;
         const unsigned char *pin = buf + lane_in;
@@ -249,22 +263,30 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
         bf16x8 wfA[3][MB], xfA[NB + 2], wfB[3][MB], xfB[NB + 2];
         SR355_LOAD_FRAGS(wfA, xfA, 0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef SR355_TRACE
+        if (a.trace && g == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        SR355_SSTAMP(3);
         // column 0: its MFMAs, the reads of column 1 and this stage's DMA issue, one of each at a time
         SR355_ISSUE_DMA(issue_slot);
         SR355_LOAD_FRAGS(wfB, xfB, 1);
         SR355_MMA_FRAGS(wfA, xfA);
         SR355_INTERLEAVE(G::N_READS, G::KMAX, 0);
         __builtin_amdgcn_sched_barrier(0);
+        SR355_SSTAMP(4);
         // column 1 under the reads of column 2
         SR355_LOAD_FRAGS(wfA, xfA, 2);
         SR355_MMA_FRAGS(wfB, xfB);
         SR355_INTERLEAVE(G::N_READS, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
+        SR355_SSTAMP(5);
         SR355_MMA_FRAGS(wfA, xfA);
         __builtin_amdgcn_sched_barrier(0);
+        SR355_SSTAMP(6);
         issue_slot = issue_slot + 1 == R ? 0 : issue_slot + 1;
         SR355_ISSUE_ADVANCE();
         slot = slot + 1 == R ? 0 : slot + 1;
+        SR355_SSTAMP(7);
 
         if (++ct_stage == S) {
             // ---- epilogue of tile ct_tile ----
@@ -303,6 +325,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     // drain the DMA still in flight (dummy stages) before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SR355_FSTAMP(15);
+#ifdef SR355_TRACE
+    if (a.trace && threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k) a.trace[(4096 + blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = st_[k];
+#endif
 #undef SR355_RSRC
 #undef SR355_TILE_SETUP
 #undef SR355_ISSUE_DMA

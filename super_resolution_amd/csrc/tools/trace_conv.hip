@@ -107,7 +107,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&bias, cout_pad * 4));
     CK(hipMalloc(&t1, f32_bytes));
     CK(hipMalloc(&t2, f32_bytes));
-    CK(hipMalloc(&trace, max_wg * 16 * 8));
+    CK(hipMalloc(&trace, 2 * max_wg * 16 * 8));
     CK(hipMemset(in, 0x3c, act_bytes));
     CK(hipMemset(w, 0x3b, w_bytes));
     CK(hipMemset(bias, 0, cout_pad * 4));
@@ -131,7 +131,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 20; ++i)
         if (launch_conv3x3_ring(a, cin_units, 0, st)) return 2;
     CK(hipStreamSynchronize(st));
-    CK(hipMemset(trace, 0, max_wg * 16 * 8));
+    CK(hipMemset(trace, 0, 2 * max_wg * 16 * 8));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -147,8 +147,8 @@ int main(int argc, char **argv) {
     CK(hipStreamSynchronize(st));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> t(max_wg * 16);
-    CK(hipMemcpy(t.data(), trace, max_wg * 16 * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> t(2 * max_wg * 16);
+    CK(hipMemcpy(t.data(), trace, 2 * max_wg * 16 * 8, hipMemcpyDeviceToHost));
     int nwg = 0;
     unsigned long long t0 = ~0ull, tend = 0;
     for (int b = 0; b < max_wg; ++b)
@@ -170,6 +170,20 @@ int main(int argc, char **argv) {
         std::sort(v.begin(), v.end());
         printf("  %-22s n=%4zu  min %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f  max %6.2f us\n", names[k], v.size(), v[0],
                v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    }
+    // in-stage stamps (shader-clock ticks) of wave 0 in steady state: medians of the deltas over the workgroups
+    const char *sn[8] = {"loop top", "vmcnt wait", "barrier", "col-0 frags landed", "col-0 mfma + col-1 reads + dma issue",
+                         "col-1 mfma + col-2 reads", "col-2 mfma", "cursor advance"};
+    for (int k = 1; k < 8; ++k) {
+        std::vector<double> v;
+        for (int b = 0; b < nwg; ++b) {
+            const unsigned long long *s = &t[(size_t)(max_wg + b) * 16];
+            if (s[0] && s[k] >= s[k - 1]) v.push_back((double)(s[k] - s[k - 1]));
+        }
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        printf("  stage: %-40s p10 %6.0f  median %6.0f  p90 %6.0f ticks\n", sn[k], v[v.size() / 10], v[v.size() / 2],
+               v[v.size() * 9 / 10]);
     }
     return 0;
 }
