@@ -49,7 +49,7 @@ extern "C" {
 #define SR355_SPLIT_WEIGHT 1
 #define SR355_SPLIT_INPUT 2
 
-#define SR355_ABI_VERSION 6
+#define SR355_ABI_VERSION 7
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -182,6 +182,16 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed_d
                             size_t packed_bytes, const float *in_nchw_dev, float *out_nchw_dev,
                             int N, int H, int W, void *workspace_dev, size_t workspace_bytes,
                             void *stream);
+
+/* The same forward between image buffers, as the reference's inference script drives it
+ * (/root/reference/esrgan/test.py:68-74): in uint8 [N][H][W][in_channels] (PIL / numpy HWC layout) read as
+ * byte / 255 (torchvision ToTensor, esrgan/dataset.py:67-68); out uint8 [N][4H][4W][out_channels] =
+ * trunc(255 * clamp(y, 0, 1)) (`.clamp(0, 1)` then ToPILImage's mul(255).byte()).  The conversions run inside
+ * the first layout kernel and conv_last's epilogue; no fp32 image is materialised. */
+int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packed_dev,
+                               size_t packed_bytes, const unsigned char *in_u8hwc_dev,
+                               unsigned char *out_u8hwc_dev, int N, int H, int W, void *workspace_dev,
+                               size_t workspace_bytes, void *stream);
 
 /* ---- training: forward that keeps activations, and the backward pass (bf16 kernels only) ----
  * Replaces what autograd records for GeneratorRRDB.forward and replays under loss.backward()

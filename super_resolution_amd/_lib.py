@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 
 # every symbol include/sr355.h declares
@@ -27,7 +27,7 @@ EXPORTS = (
     "sr355_conv3x3_fwd",
     "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
-    "sr355_generator_workspace_bytes", "sr355_generator_forward",
+    "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
     "sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes", "sr355_generator_forward_train",
     "sr355_generator_packed_bwd_bytes", "sr355_generator_pack_bwd", "sr355_generator_bwd_workspace_bytes",
     "sr355_generator_grads_floats", "sr355_generator_backward",
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
     L.sr355_generator_workspace_bytes.argtypes = [C.POINTER(GeneratorCfg), i, i, i]
     L.sr355_generator_workspace_bytes.restype = sz
     L.sr355_generator_forward.argtypes = [C.POINTER(GeneratorCfg), vp, sz, vp, vp, i, i, i, vp, sz, vp]
+    L.sr355_generator_forward_u8.argtypes = [C.POINTER(GeneratorCfg), vp, sz, vp, vp, i, i, i, vp, sz, vp]
     cfgp = C.POINTER(GeneratorCfg)
     for name in ("sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes",
                  "sr355_generator_bwd_workspace_bytes"):

@@ -482,14 +482,20 @@ static int batch_parts(int N, int H, int W) {
     return parts;
 }
 
+// Input: fp32 NCHW, or (in_u8) a uint8 HWC image batch read as byte / 255.  Output: fp32 NCHW unclamped, or (out_u8)
+// the uint8 HWC image batch the reference's inference saves (clamp, mul 255, truncate).
 static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpec> &specs, const unsigned char *pk,
                        const float *in_nchw, float *out_nchw, int N, int H, int W, const Workspace &ws,
-                       const FwdBufs &fb, hipStream_t stream) {
+                       const FwdBufs &fb, hipStream_t stream, const unsigned char *in_u8 = nullptr,
+                       unsigned char *out_u8 = nullptr) {
     const int dtype = cfg->dtype, cpu = unit_channels(dtype);
     const int nf = cfg->num_features, gc = cfg->growth_channels;
     float *T = fb.T, *R = fb.R, *F = fb.F;
-    int rc = launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units,
-                                    specs[0].split == SR355_SPLIT_INPUT, stream);
+    const int in_split = specs[0].split == SR355_SPLIT_INPUT;
+    int rc = in_u8 ? launch_u8hwc_to_blocked(in_u8, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units, in_split,
+                                             stream)
+                   : launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units, in_split,
+                                            stream);
     if (rc) return rc;
 
     // parts of the batch and the stream each runs on
@@ -516,7 +522,8 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     size_t ci = 0;  // running conv index
     auto conv = [&](const unsigned char *in, int in_units, int cin_units, int h, int w, int ups,
                     unsigned char *out_act, int out_units, int out_off, float slope, const float *res1, float s1,
-                    const float *res2, float s2, float *out_f32, float *out_nc) -> int {
+                    const float *res2, float s2, float *out_f32, float *out_nc,
+                    unsigned char *out_img = nullptr) -> int {
         const ConvSpec &sp = specs[ci++];
         const size_t in_img = (size_t)(h >> ups) * (w >> ups) * in_units * 16;
         const size_t act_img = (size_t)h * w * out_units * 16;
@@ -530,6 +537,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             a.out_act = out_act ? out_act + n0 * act_img : nullptr;
             a.out_f32 = out_f32 ? out_f32 + n0 * f32_img : nullptr;
             a.out_nchw = out_nc ? out_nc + n0 * f32_img : nullptr;
+            a.out_u8 = out_img ? out_img + n0 * f32_img : nullptr;   // same element count, one byte each
             a.res1 = res1 ? res1 + n0 * f32_img : nullptr;
             a.res2 = res2 ? res2 + n0 * f32_img : nullptr;
             a.res1_scale = s1;
@@ -592,7 +600,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                    nullptr, 0.f, nullptr, nullptr)))
         return rc;
     rc = conv(fb.H3, ws.nf_units, ws.nf_units, 4 * H, 4 * W, 0, nullptr, 0, 0, 1.f, nullptr, 0.f, nullptr, 0.f,
-              nullptr, out_nchw);
+              nullptr, out_u8 ? nullptr : out_nchw, out_u8);
     if (rc) return rc;
     for (int p = 1; p < n_parts; ++p) {   // join: the caller's stream continues after every part
         if (check_hip(hipEventRecord(ss->join[p - 1], part_stream[p]), "hipEventRecord") ||
@@ -641,6 +649,33 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
     fb.L1 = wsb + ws.L1, fb.H1 = wsb + ws.H1, fb.H2 = wsb + ws.H2, fb.H3 = wsb + ws.H3;
     return run_forward(cfg, specs, (const unsigned char *)packed, in_nchw, out_nchw, N, H, W, ws, fb,
                        (hipStream_t)stream_);
+}
+
+int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packed, size_t packed_bytes,
+                               const unsigned char *in_u8hwc, unsigned char *out_u8hwc, int N, int H, int W,
+                               void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
+    size_t total = 0;
+    std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
+    int rc = forward_checks("generator_forward_u8", cfg, packed, packed_bytes, total,
+                            reinterpret_cast<const float *>(in_u8hwc), reinterpret_cast<float *>(out_u8hwc), N, H, W);
+    if (rc) return rc;
+    const Workspace ws = carve(*cfg, N, H, W);
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < ws.total) {
+        set_error("generator_forward_u8: workspace must be 256-byte aligned and >= %zu bytes (got %zu)", ws.total,
+                  workspace_bytes);
+        return SR355_ERR_INVALID;
+    }
+    unsigned char *wsb = (unsigned char *)workspace;
+    FwdBufs fb;
+    fb.x0 = wsb + ws.x0;
+    fb.blk_base = wsb + ws.bufA;
+    fb.blk_stride = ws.bufB - ws.bufA;
+    fb.blk_count = 2;
+    fb.T = (float *)(wsb + ws.T), fb.R = (float *)(wsb + ws.R), fb.F = (float *)(wsb + ws.F);
+    fb.L1 = wsb + ws.L1, fb.H1 = wsb + ws.H1, fb.H2 = wsb + ws.H2, fb.H3 = wsb + ws.H3;
+    return run_forward(cfg, specs, (const unsigned char *)packed, nullptr, nullptr, N, H, W, ws, fb,
+                       (hipStream_t)stream_, in_u8hwc, out_u8hwc);
 }
 
 // ---- training: forward that keeps activations, backward -------------------------------------

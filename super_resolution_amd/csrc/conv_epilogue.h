@@ -70,6 +70,16 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
         for (int j = 0; j < 4; ++j)
             if (c0 + j < a.cout_real) a.out_nchw[(((size_t)n * a.cout_real + c0 + j) * H + y) * W + x] = v[j];
     }
+    if (a.out_u8) {
+        // what the reference's inference does to the output (/root/reference/esrgan/test.py:72-73): clamp(0, 1),
+        // then ToPILImage's mul(255).byte() (truncation), stored as the HWC image
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < a.cout_real) {
+                const float cl = v[j] < 0.f ? 0.f : (v[j] > 1.f ? 1.f : v[j]);
+                a.out_u8[((row * W) + x) * a.cout_real + c0 + j] = (unsigned char)(int)(cl * 255.0f);
+            }
+    }
 }
 
 }  // namespace sr355

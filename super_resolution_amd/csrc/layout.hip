@@ -15,9 +15,17 @@ template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return
 // One thread per (n, y, unit, x): gathers CPU channels from NCHW and writes one 16-byte unit.
 // split != 0 (bf16): channels [0,C) hold bf16(x) and channels [C,2C) the rounding residue
 // bf16(x - bf16(x)), so a conv over both sees x to ~16 bits.
-template <typename T>
-__global__ void nchw_to_blocked_kernel(const float *__restrict__ src, T *__restrict__ dst, int N, int C,
+// U8: src is uint8 [N][H][W][C] (an image as PIL / numpy hold it) and the value is byte / 255 in fp32, what
+// torchvision's ToTensor hands the reference (/root/reference/esrgan/test.py:69, esrgan/dataset.py:67-68).
+template <typename T, bool U8 = false>
+__global__ void nchw_to_blocked_kernel(const void *__restrict__ src_, T *__restrict__ dst, int N, int C,
                                        int H, int W, int U, int split) {
+    const float *src = static_cast<const float *>(src_);
+    const unsigned char *src8 = static_cast<const unsigned char *>(src_);
+    auto value = [&](int n, int c, int y, int x) -> float {
+        if constexpr (U8) return (float)src8[(((size_t)n * H + y) * W + x) * C + c] / 255.0f;
+        else return src[(((size_t)n * C + c) * H + y) * W + x];
+    };
     constexpr int CPU = 16 / sizeof(T);
     const size_t total = (size_t)N * H * U * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
@@ -34,9 +42,9 @@ __global__ void nchw_to_blocked_kernel(const float *__restrict__ src, T *__restr
             const int c = u * CPU + e;
             float f = 0.f;
             if (c < C) {
-                f = src[(((size_t)n * C + c) * H + y) * W + x];
+                f = value(n, c, y, x);
             } else if (split && c < 2 * C) {
-                const float full = src[(((size_t)n * C + c - C) * H + y) * W + x];
+                const float full = value(n, c - C, y, x);
                 f = full - (float)from_f32<T>(full);
             }
             v[e] = from_f32<T>(f);
@@ -133,12 +141,24 @@ int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dty
                            int dst_units, int split, hipStream_t stream) {
     const size_t total = (size_t)N * H * dst_units * W;
     if (dtype == SR355_DTYPE_BF16)
-        hipLaunchKernelGGL(nchw_to_blocked_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, stream, src,
-                           (__bf16 *)dst, N, C, H, W, dst_units, split);
+        hipLaunchKernelGGL((nchw_to_blocked_kernel<__bf16, false>), dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const void *)src, (__bf16 *)dst, N, C, H, W, dst_units, split);
     else
-        hipLaunchKernelGGL(nchw_to_blocked_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, src,
-                           (float *)dst, N, C, H, W, dst_units, 0);
+        hipLaunchKernelGGL((nchw_to_blocked_kernel<float, false>), dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const void *)src, (float *)dst, N, C, H, W, dst_units, 0);
     return check_hip(hipGetLastError(), "nchw_to_blocked launch");
+}
+
+int launch_u8hwc_to_blocked(const unsigned char *src, int N, int C, int H, int W, int dtype, void *dst,
+                            int dst_units, int split, hipStream_t stream) {
+    const size_t total = (size_t)N * H * dst_units * W;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL((nchw_to_blocked_kernel<__bf16, true>), dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const void *)src, (__bf16 *)dst, N, C, H, W, dst_units, split);
+    else
+        hipLaunchKernelGGL((nchw_to_blocked_kernel<float, true>), dim3(grid_for(total)), dim3(256), 0, stream,
+                           (const void *)src, (float *)dst, N, C, H, W, dst_units, 0);
+    return check_hip(hipGetLastError(), "u8hwc_to_blocked launch");
 }
 
 int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C, int H,

@@ -17,6 +17,7 @@ struct ConvArgs {
     unsigned char *out_act;      // blocked, may be null
     float *out_f32;              // fp32 trunk [N][H][f32_units][W][4], may be null
     float *out_nchw;             // [N][cout_real][H][W], may be null
+    unsigned char *out_u8;       // uint8 image [N][H][W][cout_real] = trunc(255 * clamp(v, 0, 1)), may be null
     const float *res1;           // fp32 trunk, may be null
     const float *res2;           // fp32 trunk, may be null
     float res1_scale, res2_scale; // v = resK_w * resK + resK_scale * v
@@ -53,6 +54,8 @@ int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream);
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
                            int dst_units, int split, hipStream_t stream);
+int launch_u8hwc_to_blocked(const unsigned char *src, int N, int C, int H, int W, int dtype, void *dst,
+                            int dst_units, int split, hipStream_t stream);
 int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C,
                            int H, int W, float *dst, hipStream_t stream);
 int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,

@@ -212,6 +212,26 @@ class GeneratorRRDB(nn.Module):
         return ops.generator_forward(xin.detach(), self.packed_parameters(), self.workspace(N, H, W, xin.device),
                                      self.cfg())
 
+    @torch.no_grad()
+    def upscale_u8(self, image: Tensor) -> Tensor:
+        """Image in, image out: uint8 ``[H, W, 3]`` or ``[N, H, W, 3]`` (the layout of ``numpy.asarray(PIL image)``)
+        on the module's device -> uint8 ``[4H, 4W, 3]`` / ``[N, 4H, 4W, 3]``.  Bit-identical to
+        ``ToPILImage()(self(ToTensor()(image)).clamp(0, 1))`` of /root/reference/esrgan/test.py:69-73, with the
+        byte -> float conversion folded into the first layout kernel and clamp / scale / truncate into conv_last's
+        store, so neither fp32 image exists in memory."""
+        single = image.dim() == 3
+        img = image.unsqueeze(0) if single else image
+        if img.dim() != 4 or img.dtype != torch.uint8 or img.shape[-1] != self.in_channels:
+            raise RuntimeError(f"expected a uint8 HWC image with {self.in_channels} channels, got "
+                               f"{tuple(image.shape)} {image.dtype}")
+        if not img.is_cuda:
+            raise RuntimeError("super_resolution_amd runs on ROCm devices only: move the image to 'cuda' "
+                               "(there is no CPU fallback)")
+        N, H, W, _c = img.shape
+        out = ops.generator_forward_u8(img.contiguous(), self.packed_parameters(),
+                                       self.workspace(N, H, W, img.device), self.cfg())
+        return out[0] if single else out
+
 
 def _graph_params(module: "GeneratorRRDB", params: List[Tensor]) -> List[Tensor]:
     """The parameters the autograd node takes as inputs: all of them, or with ``direct_grads`` one trainable

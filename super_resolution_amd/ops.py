@@ -326,6 +326,31 @@ def _(x, packed, workspace, cfg):
     return x.new_empty((N, cfg[1], 4 * H, 4 * W), dtype=torch.float32)
 
 
+@torch.library.custom_op("sr355::generator_forward_u8", mutates_args=("workspace",))
+def generator_forward_u8(image: Tensor, packed: Tensor, workspace: Tensor, cfg: List[int]) -> Tensor:
+    """The inference loop body of /root/reference/esrgan/test.py:68-74 between image buffers: uint8 [N,H,W,in]
+    (HWC, as PIL / numpy hold an image) read as byte / 255 -> uint8 [N,4H,4W,out] = trunc(255 * clamp(y, 0, 1))."""
+    _need_cuda(image, packed, workspace)
+    if image.dtype != torch.uint8 or image.dim() != 4 or not image.is_contiguous():
+        raise RuntimeError("generator_forward_u8 expects a contiguous uint8 NHWC tensor")
+    c = make_cfg(cfg)
+    N, H, W, Cin = (int(v) for v in image.shape)
+    if Cin != c.in_channels:
+        raise RuntimeError(f"generator_forward_u8: image has {Cin} channels, model expects {c.in_channels}")
+    out = torch.empty((N, 4 * H, 4 * W, c.out_channels), dtype=torch.uint8, device=image.device)
+    with torch.cuda.device(image.device):
+        check(_lib.lib().sr355_generator_forward_u8(C.byref(c), packed.data_ptr(), _nbytes(packed), image.data_ptr(),
+                                                    out.data_ptr(), N, H, W, workspace.data_ptr(),
+                                                    _nbytes(workspace), _stream()), "sr355_generator_forward_u8")
+    return out
+
+
+@generator_forward_u8.register_fake
+def _(image, packed, workspace, cfg):
+    N, H, W, _c = image.shape
+    return image.new_empty((N, 4 * H, 4 * W, cfg[1]), dtype=torch.uint8)
+
+
 # ------------------------------------------------------------------------------------
 # training: forward that keeps activations + backward
 def _size(fn_name: str, cfg: List[int], *shape: int) -> int:

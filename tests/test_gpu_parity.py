@@ -313,6 +313,40 @@ def test_generator_call_site_contract():
     assert e.requires_grad and torch.equal(e.detach(), d)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 21, 45), (1, 64, 96)])
+def test_uint8_image_path_is_the_reference_io_edge(precision, shape):
+    """esrgan/test.py:69-73: ToTensor (byte / 255, HWC -> CHW), netG, clamp(0, 1), ToPILImage (mul(255).byte(),
+    CHW -> HWC).  upscale_u8 folds both conversions into the kernels: bit-identical to the same chain around this
+    module's fp32 call, and within rounding of the oracle's fp32 run of it."""
+    sd = O.center_outputs(O.make_generator_state(51, num_blocks=2))
+    net = load_net(S.GeneratorRRDB(num_blocks=2, precision=precision), sd)
+    N, H, W = shape
+    img = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(52))
+
+    def chain(forward, image):
+        x = image.permute(0, 3, 1, 2).float().div(255)      # ToTensor runs on the CPU (a true division)
+        return forward(x).clamp(0, 1).mul(255).byte().permute(0, 2, 3, 1).contiguous()
+
+    with torch.no_grad():
+        got = net.upscale_u8(img.to(DEV))
+        same_kernels = chain(lambda x: net(x.to(DEV)), img)
+        ref = chain(lambda x: O.generator_forward(sd, x), img)
+    assert got.dtype == torch.uint8 and got.shape == (N, 4 * H, 4 * W, 3)
+    assert torch.equal(got, same_kernels)
+    diff = (got.cpu().int() - ref.int()).abs()
+    equal = (diff == 0).float().mean().item()
+    print(f"uint8 path {precision} {shape}: {equal:.4f} of the bytes equal the oracle's, max |diff| {diff.max().item()}")
+    if precision == "fp32":
+        assert diff.max().item() <= 1 and equal > 0.999
+    else:
+        assert diff.max().item() <= 2 and equal > 0.95
+    one = net.upscale_u8(img[0].to(DEV))          # a single HWC image
+    assert one.shape == (4 * H, 4 * W, 3) and torch.equal(one, got[0])
+    with pytest.raises(RuntimeError):
+        net.upscale_u8(img.float().to(DEV))
+
+
 def test_config2_size_properties():
     """BASELINE config 2 (16 x 3x128x128, bf16, 23 blocks): the oracle takes minutes per batch on CPU,
     so the full size is checked through size-independent properties plus one oracle-checked image."""
