@@ -249,12 +249,9 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
     netG = S.GeneratorRRDB(precision="bf16").to(dev).train()
     modelG = DistributedGenerator(netG) if world > 1 else netG
     def adam(params):
-        # the reference's optimizer (train.py:117-122); fused=True is the same update as one multi-tensor launch
-        # instead of a handful of launches per parameter group slice (the step is bound by host launch issue)
-        try:
-            return torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999), fused=True), "Adam(1e-4, betas 0.9/0.999, fused)"
-        except (RuntimeError, TypeError):
-            return torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999)), "Adam(1e-4, betas 0.9/0.999)"
+        # the reference's optimizer (train.py:117-122) as one launch over a flat parameter buffer: the same update
+        # (tests/test_gpu_training.py::test_flat_adam_is_torch_adam), without the per-tensor host work of torch's Adam
+        return S.FlatAdam(params, lr=1e-4, betas=(0.9, 0.999)), "FlatAdam(1e-4, betas 0.9/0.999) = torch.optim.Adam's update in one launch"
 
     optG, opt_name = adam(netG.parameters())
     lr = torch.rand(16, 3, 32, 32, device=dev)

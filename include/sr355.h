@@ -193,6 +193,16 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
                                unsigned char *out_u8hwc_dev, int N, int H, int W, void *workspace_dev,
                                size_t workspace_bytes, void *stream);
 
+/* One Adam update over flat fp32 device buffers of n elements, in one launch: the arithmetic of
+ * torch.optim.Adam(lr, betas) as the reference configures it (/root/reference/esrgan/train.py:117-122; no amsgrad,
+ * weight_decay added to the gradient when non-zero).  `step` is the 1-based count of this update (bias corrections
+ * 1 - beta^step are taken on the host in double).  The generator backward already delivers every gradient as one
+ * flat buffer in state_dict order; with the parameters kept in one buffer of the same order, the optimizer tail
+ * of a training iteration is this single call instead of a pass over 702 tensors. */
+int sr355_adam_step(float *param_dev, const float *grad_dev, float *exp_avg_dev, float *exp_avg_sq_dev, size_t n,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                    void *stream);
+
 /* ---- training: forward that keeps activations, and the backward pass (bf16 kernels only) ----
  * Replaces what autograd records for GeneratorRRDB.forward and replays under loss.backward()
  * (/root/reference/esrgan/train.py:159-161, :212-220). */

@@ -4,7 +4,8 @@ from . import ops  # noqa: F401  (registers the sr355:: torch.library ops)
 from .esrgan_model import GeneratorRRDB, RRDB, RRDBNet, ResidualDenseBlock  # noqa: F401
 from .esrgan_aux import Discriminator, VGGFeatureExtractor, adversarial_step, pixel_step  # noqa: F401
 from .sharded import sharded_forward, tiled_forward  # noqa: F401
+from .optim import FlatAdam  # noqa: F401
 
 __all__ = ["GeneratorRRDB", "RRDBNet", "RRDB", "ResidualDenseBlock", "Discriminator", "VGGFeatureExtractor",
-           "pixel_step", "adversarial_step", "sharded_forward", "tiled_forward", "ops", "build",
+           "pixel_step", "adversarial_step", "FlatAdam", "sharded_forward", "tiled_forward", "ops", "build",
            "DTYPE_BF16", "DTYPE_F32", "LIB_PATH", "Sr355Error"]

@@ -32,6 +32,7 @@ EXPORTS = (
     "sr355_generator_packed_bwd_bytes", "sr355_generator_pack_bwd", "sr355_generator_bwd_workspace_bytes",
     "sr355_generator_grads_floats", "sr355_generator_backward",
     "sr355_generator_backward_phases", "sr355_generator_backward_range",
+    "sr355_adam_step",
 )
 
 
@@ -126,6 +127,7 @@ def lib() -> C.CDLL:
     L.sr355_generator_workspace_bytes.argtypes = [C.POINTER(GeneratorCfg), i, i, i]
     L.sr355_generator_workspace_bytes.restype = sz
     L.sr355_generator_forward.argtypes = [C.POINTER(GeneratorCfg), vp, sz, vp, vp, i, i, i, vp, sz, vp]
+    L.sr355_adam_step.argtypes = [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, vp]
     L.sr355_generator_forward_u8.argtypes = [C.POINTER(GeneratorCfg), vp, sz, vp, vp, i, i, i, vp, sz, vp]
     cfgp = C.POINTER(GeneratorCfg)
     for name in ("sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes",

@@ -678,6 +678,22 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
                        (hipStream_t)stream_, in_u8hwc, out_u8hwc);
 }
 
+int sr355_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int step, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1 || !(beta1 >= 0. && beta1 < 1.) ||
+        !(beta2 >= 0. && beta2 < 1.) || !aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) ||
+        !aligned16(exp_avg_sq)) {
+        set_error("adam_step: bad arguments (n=%zu step=%d betas %g %g; buffers must be 16-byte aligned)", n, step,
+                  (double)beta1, (double)beta2);
+        return SR355_ERR_INVALID;
+    }
+    if (n == 0) return SR355_OK;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    return launch_adam_flat(param, grad, exp_avg, exp_avg_sq, n, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                            (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(lr / bc1), (float)sqrt(bc2),
+                            (hipStream_t)stream);
+}
+
 // ---- training: forward that keeps activations, backward -------------------------------------
 // Saved activations (bf16 path only): blocked input, one dense-block buffer per dense block plus the
 // body output, the LR feature map fed to upconv1 and the three HR activations.

@@ -288,7 +288,13 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
         const long long tiles = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
         if (force == 1 || (force != 0 && tiles >= 192)) return launch_conv3x3_ring(a, cin_units, weight_split, stream);
     }
-    const bool wide = (a.cout_pad % 64) == 0;
+    bool wide = (a.cout_pad % 64) == 0;
+    if (wide && dtype == SR355_DTYPE_BF16) {
+        // too few tiles to give every CU a workgroup: one workgroup per 32 output channels instead of 64
+        static const int split_knob = [] { const char *e = getenv("SR355_SMALL_SPLIT"); return e ? atoi(e) : 1; }();
+        const long long blocks4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.cout_pad / 64);
+        if (split_knob && blocks4 < 256) wide = false;
+    }
     if (dtype == SR355_DTYPE_BF16)
         return wide ? launch_nb<__bf16, 2, 2>(b, stream) : launch_nb<__bf16, 1, 2>(b, stream);
     if (dtype == SR355_DTYPE_F32)

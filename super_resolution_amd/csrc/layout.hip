@@ -186,6 +186,45 @@ int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int
     return check_hip(hipGetLastError(), "pack_weight launch");
 }
 
+// Adam over flat fp32 buffers (torch.optim.Adam without amsgrad / maximize, the optimizer of
+// /root/reference/esrgan/train.py:117-122), four elements per thread; `step_size` = lr / (1 - beta1^t) and
+// `bc2_sqrt` = sqrt(1 - beta2^t) come from the host, as do omb1 = 1 - beta1 and omb2 = 1 - beta2 (taken in double,
+// as torch takes them, before rounding to fp32).
+__global__ void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                 float *__restrict__ v, size_t n, float beta1, float beta2, float omb1,
+                                 float omb2, float eps, float weight_decay, float step_size, float bc2_sqrt) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    auto one = [&](float &pp, float gg, float &mm, float &vv) {
+        if (weight_decay != 0.f) gg += weight_decay * pp;
+        mm = mm + (gg - mm) * omb1;
+        vv = vv * beta2 + omb2 * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp -= step_size * (mm / denom);
+    };
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i],
+               vv = reinterpret_cast<float4 *>(v)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        one(pp.x, gg.x, mm.x, vv.x);
+        one(pp.y, gg.y, mm.y, vv.y);
+        one(pp.z, gg.z, mm.z, vv.z);
+        one(pp.w, gg.w, mm.w, vv.w);
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride)
+        one(p[i], g[i], m[i], v[i]);
+}
+
+int launch_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float beta1, float beta2, float omb1,
+                     float omb2, float eps, float weight_decay, float step_size, float bc2_sqrt, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v, n, beta1,
+                       beta2, omb1, omb2, eps, weight_decay, step_size, bc2_sqrt);
+    return check_hip(hipGetLastError(), "adam_flat launch");
+}
+
 int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t stream) {
     for (int at = 0; at < n; at += PACK_BATCH) {
         PackJobTable t;

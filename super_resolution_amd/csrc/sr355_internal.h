@@ -56,6 +56,8 @@ int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dty
                            int dst_units, int split, hipStream_t stream);
 int launch_u8hwc_to_blocked(const unsigned char *src, int N, int C, int H, int W, int dtype, void *dst,
                             int dst_units, int split, hipStream_t stream);
+int launch_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float beta1, float beta2, float omb1,
+                     float omb2, float eps, float weight_decay, float step_size, float bc2_sqrt, hipStream_t stream);
 int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dtype, int N, int C,
                            int H, int W, float *dst, hipStream_t stream);
 int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,

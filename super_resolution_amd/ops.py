@@ -473,3 +473,20 @@ def generator_backward_range(grad_out: Tensor, packed_bwd: Tensor, saved: Tensor
 @generator_backward_range.register_fake
 def _(grad_out, packed_bwd, saved, workspace, grads, grad_in, cfg, lr_height, lr_width, phase_begin, phase_end):
     return None
+
+
+# ------------------------------------------------------------------------------------
+# optimizer tail
+@torch.library.custom_op("sr355::adam_step", mutates_args=("param", "exp_avg", "exp_avg_sq"))
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
+              beta2: float, eps: float, weight_decay: float, step: int) -> None:
+    """One torch.optim.Adam update (esrgan/train.py:117-122) over flat fp32 buffers, one launch."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("adam_step expects four contiguous fp32 tensors of one length")
+    with torch.cuda.device(param.device):
+        check(_lib.lib().sr355_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                         exp_avg_sq.data_ptr(), n, lr, beta1, beta2, eps, weight_decay, step,
+                                         _stream()), "sr355_adam_step")

@@ -167,6 +167,85 @@ def test_direct_and_per_parameter_gradient_delivery_agree():
     assert torch.equal(gw, grads[1]["conv_last.weight"])
 
 
+def test_flat_adam_is_torch_adam():
+    """train.py:117-122: Adam(lr 1e-4, betas 0.9/0.999).  FlatAdam keeps the parameters in one buffer and updates
+    them in one launch.  Fed the same gradients for five steps it must leave the same weights as torch.optim.Adam;
+    its state_dict loads into torch's Adam layout and back; a frozen parameter stays untouched; after the
+    generator's own backward the gradients are used in place."""
+    sd = O.make_generator_state(45, num_blocks=1)
+    nets, opts = [], []
+    for flat in (False, True):
+        net = make_net(sd, 1)
+        net.upconv1.bias.requires_grad_(False)
+        opt = (S.FlatAdam if flat else torch.optim.Adam)(net.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        nets.append(net), opts.append(opt)
+    keys = list(nets[1].state_dict().keys())
+
+    def feed(step, pairs):
+        gen = torch.Generator().manual_seed(100 + step)
+        for k, p in nets[0].named_parameters():
+            g = torch.randn(p.shape, generator=gen) * (10.0 ** torch.randint(-9, 1, (1,), generator=gen).item())
+            for net, opt in pairs:
+                q = dict(net.named_parameters())[k]
+                q.grad = g.to(DEV) if q.requires_grad else None
+        for _net, opt in pairs:
+            opt.step()
+
+    for step in range(5):
+        feed(step, list(zip(nets, opts)))
+    assert list(nets[1].state_dict().keys()) == keys
+    for (k, a), (_, b) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert (a - b).abs().max().item() <= 2e-6, k               # five updates of about 1e-3 each
+    assert torch.equal(nets[1].upconv1.bias.cpu(), sd["upconv1.bias"])
+    # state_dict interchange with torch.optim.Adam, both ways
+    ref_state, mine = opts[0].state_dict(), opts[1].state_dict()
+    assert mine["param_groups"][0]["lr"] == 1e-3 and len(mine["state"]) == len(ref_state["state"])
+    for k0 in ref_state["state"]:
+        assert float(mine["state"][k0]["step"]) == 5.0 == float(ref_state["state"][k0]["step"])
+        assert rel_l2(mine["state"][k0]["exp_avg"], ref_state["state"][k0]["exp_avg"]) < 1e-5
+        assert rel_l2(mine["state"][k0]["exp_avg_sq"], ref_state["state"][k0]["exp_avg_sq"]) < 1e-5
+    fresh = make_net(sd, 1)
+    fresh.load_state_dict(nets[0].state_dict())
+    fresh.upconv1.bias.requires_grad_(False)
+    opt2 = S.FlatAdam(fresh.parameters(), lr=1e-3)
+    opt2.load_state_dict(ref_state)
+    plain = torch.optim.Adam(nets[1].parameters(), lr=1e-3)
+    plain.load_state_dict(mine)
+    nets.append(fresh), opts.append(opt2)
+    feed(5, [(nets[0], opts[0]), (fresh, opt2), (nets[1], plain)])
+    for (k, p), (_, q), (_, r) in zip(nets[0].named_parameters(), fresh.named_parameters(), nets[1].named_parameters()):
+        assert (p - q).abs().max().item() <= 3e-6 and (p - r).abs().max().item() <= 3e-6, k
+
+    # on the generator's own backward: same first update as torch's Adam, gradients taken in place, loss falls
+    gen = torch.Generator().manual_seed(46)
+    lr_batch = torch.rand(2, 3, 8, 12, generator=gen).to(DEV)
+    hr_batch = torch.rand(2, 3, 32, 48, generator=gen).to(DEV)
+    na, nb = make_net(sd, 1), make_net(sd, 1)
+    oa, ob = torch.optim.Adam(na.parameters(), lr=1e-4), S.FlatAdam(nb.parameters(), lr=1e-4)
+    la = S.pixel_step(na, oa, lr_batch, hr_batch)["loss_pix"].item()
+    lb = S.pixel_step(nb, ob, lr_batch, hr_batch)["loss_pix"].item()
+    assert la == lb
+    for (k, p), (_, q) in zip(na.named_parameters(), nb.named_parameters()):
+        assert (p - q).abs().max().item() <= 1e-7, k
+    assert ob._groups[0].scratch is None
+    for _ in range(4):
+        lb2 = S.pixel_step(nb, ob, lr_batch, hr_batch)["loss_pix"].item()
+    assert lb2 < lb and ob._groups[0].scratch is None
+    # weight decay, plain torch module (gradients gathered)
+    lin = torch.nn.Linear(5, 3).to(DEV)
+    lin2 = torch.nn.Linear(5, 3).to(DEV)
+    lin2.load_state_dict(lin.state_dict())
+    o1 = torch.optim.Adam(lin.parameters(), lr=1e-2, weight_decay=0.1)
+    o2 = S.FlatAdam(lin2.parameters(), lr=1e-2, weight_decay=0.1)
+    xb = torch.rand(4, 5, device=DEV)
+    for _ in range(3):
+        for m, o in ((lin, o1), (lin2, o2)):
+            o.zero_grad(set_to_none=True)
+            m(xb).square().mean().backward()
+            o.step()
+    assert (lin.weight - lin2.weight).abs().max().item() < 1e-6 and (lin.bias - lin2.bias).abs().max().item() < 1e-6
+
+
 def test_backward_full_depth_small_patch(golden):
     g = golden("g4_gen23.npz")
     sd = O.center_outputs(O.make_generator_state(int(g["seed"])), float(g["bias_shift"]))

@@ -20,7 +20,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = S.GeneratorRRDB().to(dev).train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = S.FlatAdam(net.parameters(), lr=1e-4)          # torch.optim.Adam's update in one launch
     lr = torch.rand(B, 3, L, L, device=dev)
     hr = torch.rand(B, 3, 4 * L, 4 * L, device=dev)
 
