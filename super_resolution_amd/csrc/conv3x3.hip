@@ -267,6 +267,22 @@ static int launch_nb(const ConvArgs &a, hipStream_t stream) {
     return launch_inst<T, MB, 1, SU>(a, stream);
 }
 
+// bf16 at small tile counts: with 4-row tiles a stage is 9*MB MFMAs per wave against one global-load latency, so the
+// K loop is latency-bound; stages of four units (32 channels) halve the number of those latencies.
+template <int MB>
+static int launch_bf16(const ConvArgs &a, int cin_units, int weight_split, hipStream_t stream) {
+    const long long tx = (a.W + 31) / 32;
+    const long long cblk = a.cout_pad / (32 * MB);
+    static const int su4 = [] { const char *e = getenv("SR355_SMALL_SU4"); return e ? atoi(e) : 1; }();
+    if (su4 && (cin_units % 4) == 0 && (long long)a.N * tx * ((a.H + 7) / 8) * cblk < 512) {
+        ConvArgs b = a;
+        b.n_real_stages = cin_units / 4;
+        b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
+        return launch_inst<__bf16, MB, 1, 4>(b, stream);
+    }
+    return launch_nb<__bf16, MB, 2>(a, stream);
+}
+
 int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split, hipStream_t stream) {
     if (cin_units <= 0 || (cin_units & 1)) {
         set_error("conv3x3: cin_units=%d must be a positive even number", cin_units);
@@ -296,7 +312,7 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
         if (split_knob && blocks4 < 256) wide = false;
     }
     if (dtype == SR355_DTYPE_BF16)
-        return wide ? launch_nb<__bf16, 2, 2>(b, stream) : launch_nb<__bf16, 1, 2>(b, stream);
+        return wide ? launch_bf16<2>(b, cin_units, weight_split, stream) : launch_bf16<1>(b, cin_units, weight_split, stream);
     if (dtype == SR355_DTYPE_F32)
         return wide ? launch_nb<float, 2, 2>(b, stream) : launch_nb<float, 1, 2>(b, stream);
     set_error("conv3x3: unknown dtype %d", dtype);
