@@ -171,6 +171,13 @@ def cpu_baseline(H, W):
                       f"{med:.3f} s each, torch CPU threads={cores}"}
 
 
+def _max_over_ranks(seconds, dev, dist):
+    # RCCL reduces device tensors; the gloo rehearsal reduces on the host
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def _timed_steps(step, dev, dist, steps, warmup):
     def sync():
         if dist is not None:
@@ -186,9 +193,7 @@ def _timed_steps(step, dev, dist, steps, warmup):
     sync()
     el = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
+        el = _max_over_ranks(el, dev, dist)
     return el
 
 
@@ -242,16 +247,22 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
     * the adversarial iteration (:196-223: D update on (hr, fake), then G update with L1 + 0.01 VGG-L1 + 1e-3 GAN loss),
       VGG19 with seeded random weights (throughput does not depend on the weights).
     With more than one rank the generator's gradients go through the bucketed all-reduce overlapped with its backward
-    and the discriminator's through torch's DistributedDataParallel."""
+    and the discriminator's through one all-reduce of its flat gradient buffer in front of its optimizer step."""
     import super_resolution_amd as S
     from super_resolution_amd.ddp import DistributedGenerator
+
+    def note(msg):          # progress on stderr: the multi-rank path has collectives a stalled peer can block
+        if world > 1:
+            print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
     torch.manual_seed(0)
     netG = S.GeneratorRRDB(precision="bf16").to(dev).train()
     modelG = DistributedGenerator(netG) if world > 1 else netG
-    def adam(params):
+    def adam(params, reduce_group=None):
         # the reference's optimizer (train.py:117-122) as one launch over a flat parameter buffer: the same update
         # (tests/test_gpu_training.py::test_flat_adam_is_torch_adam), without the per-tensor host work of torch's Adam
-        return S.FlatAdam(params, lr=1e-4, betas=(0.9, 0.999)), "FlatAdam(1e-4, betas 0.9/0.999) = torch.optim.Adam's update in one launch"
+        return (S.FlatAdam(params, lr=1e-4, betas=(0.9, 0.999), reduce_group=reduce_group),
+                "FlatAdam(1e-4, betas 0.9/0.999) = torch.optim.Adam's update in one launch")
 
     optG, opt_name = adam(netG.parameters())
     lr = torch.rand(16, 3, 32, 32, device=dev)
@@ -261,7 +272,9 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
     def pixel():
         losses.update(S.pixel_step(modelG, optG, lr, hr))
 
+    note("pixel iterations")
     el = _timed_steps(pixel, dev, dist, steps, warmup)
+    note("pixel iterations done")
     assert bool(torch.isfinite(losses["loss_pix"]))
     flop = 3 * FLOP_PER_LR_PIXEL * 16 * 32 * 32          # backward = 2 forward-equivalents
     out = {"pixel_step": {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
@@ -274,14 +287,14 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
         netD = S.Discriminator().to(dev).train()
         vgg = S.VGGFeatureExtractor(pretrained=False).to(dev)
         modelD = netD
-        if world > 1:
-            modelD = torch.nn.parallel.DistributedDataParallel(netD, device_ids=[dev.index])
-        optD, _ = adam(netD.parameters())
+        optD, _ = adam(netD.parameters(), dist.group.WORLD if world > 1 else None)
 
         def adversarial():
             losses.update(S.adversarial_step(modelG, modelD, vgg, optG, optD, lr, hr))
 
+        note("adversarial iterations")
         el = _timed_steps(adversarial, dev, dist, steps, warmup)
+        note("adversarial iterations done")
         assert bool(torch.isfinite(losses["loss_G"])) and bool(torch.isfinite(losses["loss_D"]))
         out["adversarial_step"] = {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
                                    "ms_per_step": round(el / steps * 1e3, 2),
@@ -319,13 +332,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the multi-rank path on a one-GPU box: SR355_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # uses gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearsal = world > 1 and os.environ.get("SR355_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.streams > 0:
         os.environ["SR355_STREAMS"] = str(args.streams)      # read once, when the library first runs a forward
@@ -351,9 +371,7 @@ def main():
         elapsed = time.perf_counter() - t0
     assert out.shape == (B, 3, 4 * H, 4 * W) and bool(torch.isfinite(out).all())
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = _max_over_ranks(elapsed, dev, dist)
 
     ms = elapsed / args.steps * 1e3
     hr_mpix = world * B * 16 * H * W * args.steps / elapsed / 1e6
@@ -367,14 +385,14 @@ def main():
                    "streams_per_gpu": args.streams if args.streams > 0 else 2},
         "generator_tflops": round(world * B * H * W * FLOP_PER_LR_PIXEL * args.steps / elapsed / 1e12, 1),
     }
-    if rank == 0 and world == 1:
+    if rank == 0:
         if not args.no_roofline:
             with torch.no_grad():
                 roof, other, per_shape = roofline_from(measure_kernels(net, B, H, W))
             line["roofline"] = roof
             line["roofline_other_kernels"] = other
             line["kernel_shapes"] = per_shape
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W)
     hung = False
     if not args.no_train:
@@ -399,9 +417,9 @@ def main():
 
             th = threading.Thread(target=work, daemon=True)
             th.start()
-            th.join(timeout=240.0)
+            th.join(timeout=150.0)
             hung = th.is_alive()
-            line["train"] = {"error": "training extras did not finish within 240 s"} if hung else box["train"]
+            line["train"] = {"error": "training extras did not finish within 150 s"} if hung else box["train"]
     if rank == 0:
         print(json.dumps(line), flush=True)
     if hung:

@@ -93,6 +93,34 @@ def reduce_in_buckets(flat: Tensor, buckets: Sequence[Tuple[int, int, int, int]]
             view.div_(world)
 
 
+def all_reduce_mean(t: Tensor, group=None) -> None:
+    """In-place mean of ``t`` over the ranks of ``group``: one RCCL all-reduce (``backend="nccl"``); on gloo a device
+    tensor is staged through host memory (gloo's own device-tensor collectives stall when ranks share a GPU)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        return
+    host = t.cpu() if t.is_cuda else t
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    host.div_(world)
+    if host is not t:
+        t.copy_(host)
+
+
+def broadcast_tensors(tensors, src: int = 0, group=None) -> None:
+    """Rank ``src``'s values into every rank's tensors (parameters and buffers of a replica at start-up)."""
+    import torch.distributed as dist
+    staged = dist.get_backend(group) != "nccl"
+    for t in tensors:
+        if staged and t.is_cuda:
+            host = t.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.detach().copy_(host)
+        else:
+            dist.broadcast(t.detach(), src=src, group=group)
+
+
 class DistributedGenerator(nn.Module):
     """Wraps a ``GeneratorRRDB`` replica.  ``forward`` is the module's own; in grad mode the backward pass
     all-reduces the gradients bucket by bucket while it runs.  Call ``broadcast_parameters()`` once after

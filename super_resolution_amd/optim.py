@@ -26,9 +26,16 @@ class FlatAdam(torch.optim.Optimizer):
 
     Construct it after the module is on its device, as with any optimizer.  Parameters with ``requires_grad=False``
     are left alone; a trainable parameter whose ``.grad`` is ``None`` at ``step()`` while others have gradients
-    is an error (torch's Adam would skip it; a flat update cannot)."""
+    is an error (torch's Adam would skip it; a flat update cannot).
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    ``reduce_group``: a ``torch.distributed`` process group over which the gradients are averaged before every
+    update, as ONE all-reduce of the flat gradient buffer per parameter group (data-parallel training of a module
+    whose backward does not reduce its gradients itself, e.g. the discriminator: the replacement of
+    ``nn.DataParallel(netD)`` at /root/reference/esrgan/train.py:108-111 with one process per GPU)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 reduce_group=None):
+        self._reduce_group = reduce_group
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -128,6 +135,9 @@ class FlatAdam(torch.optim.Optimizer):
             grad = self._flat_grad(fg)
             if grad is None:
                 continue
+            if self._reduce_group is not None:
+                from .ddp import all_reduce_mean
+                all_reduce_mean(grad, self._reduce_group)                    # in place: .grad holds the mean after it
             fg.step += 1
             fg.step_t.fill_(float(fg.step))
             b1, b2 = group["betas"]

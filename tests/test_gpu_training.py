@@ -308,6 +308,27 @@ def _ddp_worker(rank, world, port, ret):
         worst = max(rel_l2(got[k].cpu(), (acc[k] / world).cpu()) for k in got)
         ret["worst"] = worst
         ret["buckets"] = len(dnet.buckets)
+    # one adversarial iteration across the ranks (train.py:196-223 under data parallelism): the generator reduces
+    # inside its backward, the discriminator through its optimizer's single all-reduce; replicas must stay equal
+    netD = S.Discriminator().to(DEV).train()
+    vgg = S.VGGFeatureExtractor(pretrained=False).to(DEV)
+    from super_resolution_amd.ddp import broadcast_tensors
+    broadcast_tensors(list(netD.parameters()) + list(netD.buffers()) + list(vgg.parameters()))
+    optG = S.FlatAdam(net.parameters(), lr=1e-4)
+    optD = S.FlatAdam(netD.parameters(), lr=1e-4, reduce_group=dist.group.WORLD)
+    lr_b = torch.rand(world, 2, 3, 32, 32, generator=torch.Generator().manual_seed(53)).to(DEV)
+    hr_b = torch.rand(world, 2, 3, 128, 128, generator=torch.Generator().manual_seed(54)).to(DEV)
+    out = S.adversarial_step(dnet, netD, vgg, optG, optD, lr_b[rank], hr_b[rank])
+    flatD = torch.cat([p.detach().flatten() for p in netD.parameters()])
+    flatG = torch.cat([p.detach().flatten() for p in net.parameters()])
+    flatD, flatG = flatD.cpu(), flatG.cpu()              # gloo: collectives on host tensors
+    both = [torch.empty_like(flatD) for _ in range(world)]
+    dist.all_gather(both, flatD)
+    bothG = [torch.empty_like(flatG) for _ in range(world)]
+    dist.all_gather(bothG, flatG)
+    if rank == 0:
+        ret["replicas_equal"] = bool(torch.equal(both[0], both[1]) and torch.equal(bothG[0], bothG[1]))
+        ret["losses_finite"] = bool(torch.isfinite(out["loss_G"]) and torch.isfinite(out["loss_D"]))
     dist.destroy_process_group()
 
 
@@ -321,3 +342,4 @@ def test_data_parallel_backward_two_ranks_one_gpu():
     mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["buckets"] >= 2
     assert ret["worst"] < 1e-5, ret["worst"]     # same kernels, same order: only the mean differs in rounding
+    assert ret["losses_finite"] and ret["replicas_equal"]
