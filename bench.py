@@ -73,13 +73,16 @@ def measure_kernels(net, N, H, W, forwards=3):
         wp, bp = packed[k]
         cu = (nf + k * gc) // 8
         tk = timed(3 * nb, buf, cu, wp, bp, gc, 0.2, 0, None, 0.0, None, 0.0, buf, cu, None, None)
-        rows.append(("MB1", f"conv{k + 1} {nf + k * gc}->{gc}", 3 * nb, conv_flops(nf + k * gc, gc, P), tk))
+        rows.append(("MB1", f"conv{k + 1} {nf + k * gc}->{gc}", 3 * nb, conv_flops(nf + k * gc, gc, P), tk,
+                     conv_bytes(nf + k * gc, gc, P)))
     wp, bp = packed[4]
     cu = (nf + 4 * gc) // 8
     t5 = timed(2 * nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None)
-    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5))
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5,
+                 conv_bytes(nf + 4 * gc, nf, P, skips=1, f32_out=True)))
     t5b = timed(nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None)
-    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b))
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b,
+                 conv_bytes(nf + 4 * gc, nf, P, skips=2, f32_out=True)))
     # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
     sp = 1 if net.hr_split else 0   # HR-side convs carry the weight rounding residue (2x MFMA work)
     wt, bt = ops.pack_weight(net.trunk_conv.weight.detach(), net.trunk_conv.bias.detach(), dt)
@@ -92,22 +95,31 @@ def measure_kernels(net, N, H, W, forwards=3):
     out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
     nu = nf // 8
     ta = timed(1, lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, sp)
-    rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta))
+    rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta, conv_bytes(nf, nf, 4 * P, P)))
     tb = timed(1, h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, sp)
-    rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb))
+    rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb, conv_bytes(nf, nf, 16 * P, 4 * P)))
     tc = timed(1, h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, sp)
-    rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc))
+    rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc, conv_bytes(nf, nf, 16 * P)))
     td = timed(1, h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, sp)
-    rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td))
+    rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td,
+                 conv_bytes(nf, net.out_channels, 16 * P, bf16_out=False, nchw_out=net.out_channels)))
     tt = timed(1, buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None)
-    rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt))
+    rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt, conv_bytes(nf, nf, P, skips=1)))
     return rows
+
+
+def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=True, nchw_out=0):
+    """Algorithmic HBM bytes of one launch: bf16 input read once, bf16 output, fp32 skip reads / carrier write,
+    fp32 NCHW image (weights, a few hundred KB, not counted)."""
+    p_in = p_out if p_in is None else p_in
+    return (2 * cin * p_in + (2 * cout * p_out if bf16_out else 0) + 4 * cout * p_out * skips +
+            (4 * cout * p_out if f32_out else 0) + 4 * nchw_out * p_out)
 
 
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -121,15 +133,16 @@ def measured_traffic(symbol_fragment):
 
 def roofline_from(rows):
     agg = {}
-    for sym, _name, cnt, fl, sec in rows:
-        a = agg.setdefault(sym, [0, 0.0, 0.0])
+    for sym, _name, cnt, fl, sec, nbytes in rows:
+        a = agg.setdefault(sym, [0, 0.0, 0.0, 0.0])
         a[0] += cnt
         a[1] += cnt * fl
         a[2] += cnt * sec
+        a[3] += cnt * nbytes
     out = {}
-    for sym, (cnt, fl, sec) in agg.items():
-        out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6,
-                    "flop_per_launch": fl / cnt, "achieved": fl / sec / 1e12, "time_s": sec}
+    for sym, (cnt, fl, sec, nbytes) in agg.items():
+        out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6, "flop_per_launch": fl / cnt,
+                    "achieved": fl / sec / 1e12, "time_s": sec, "bytes_per_launch": nbytes / cnt}
     dom = max(out, key=lambda s: out[s]["time_s"])
     names = {"MB1": "conv3x3_fine<MB=1,NB=4,R=2> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2> (Cout=64)"}
     d = out[dom]
@@ -137,17 +150,17 @@ def roofline_from(rows):
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r01e_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
+            "traffic_source": "profiles/r01f_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
                               "of this command with --streams 1)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
-            "flop_per_launch": d["flop_per_launch"],
+            "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),
             "how": "whole-batch launches of every conv shape of one forward, in the forward's launch mix, back to back on "
                    "one stream between two HIP events; the timed forwards themselves run two half-batches on two "
                    "streams, where launches overlap and a per-launch duration is not a kernel rate"}
     other = {names[s]: {"achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / PEAK_BF16_TFLOPS, 4),
                         "avg_launch_us": round(v["avg_launch_us"], 2)} for s, v in out.items() if s != dom}
     per_shape = [{"kernel": sym, "shape": name, "us": round(sec * 1e6, 2), "tflops": round(fl / sec / 1e12, 1)}
-                 for sym, name, _c, fl, sec in rows]
+                 for sym, name, _c, fl, sec, _b in rows]
     return roof, other, per_shape
 
 
