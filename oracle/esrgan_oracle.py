@@ -359,6 +359,47 @@ def adversarial_step(sd_g: StateDict, sd_d: StateDict, sd_v: StateDict, lr_img: 
 # --------------------------------------------------------------------------
 # metrics used by the parity gates
 # --------------------------------------------------------------------------
+# ---- CycleGAN super-resolution generator (CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-137; v2 is the same network) ----
+def generator_sr_layout(in_channels: int = 3, out_channels: int = 3, num_residual: int = 6,
+                        base_channels: int = 64) -> List[Tuple[str, int, int, int]]:
+    """(state_dict prefix, cin, cout, kernel) of every conv in construction order (CycleGAN.py:105-127)."""
+    b = base_channels
+    convs = [("conv1.0", in_channels, b, 7)]
+    for i in range(num_residual):
+        convs += [(f"res_blocks.{i}.conv1", b, b, 3), (f"res_blocks.{i}.conv2", b, b, 3)]
+    convs += [("up1.0", b, 4 * b, 3), ("up2.0", b, 4 * b, 3), ("conv_out", b, out_channels, 7)]
+    return convs
+
+
+def make_generator_sr_state(seed: int, **cfg) -> StateDict:
+    """The weights ``torch.manual_seed(seed); GeneratorSR(**cfg)`` holds (default Conv2d initialisation, drawn
+    in construction order)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = OrderedDict()
+    for name, cin, cout, k in generator_sr_layout(**cfg):
+        fan_in = cin * k * k
+        w_bound = math.sqrt(3.0) * (math.sqrt(2.0 / (1 + 5.0)) / math.sqrt(fan_in))
+        sd[name + ".weight"] = torch.empty(cout, cin, k, k).uniform_(-w_bound, w_bound, generator=gen)
+        sd[name + ".bias"] = torch.empty(cout).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=gen)
+    return sd
+
+
+def generator_sr_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
+    """GeneratorSR.forward (CycleGAN.py:129-137): 7x7 conv + ReLU, residual blocks ``x + conv2(relu(conv1(x)))``
+    (:96-100), two (3x3 conv to 4x channels, PixelShuffle(2), ReLU) stages, 7x7 conv, tanh."""
+    F = torch.nn.functional
+    h = F.relu(F.conv2d(x, sd["conv1.0.weight"], sd["conv1.0.bias"], padding=3))
+    i = 0
+    while f"res_blocks.{i}.conv1.weight" in sd:
+        p = f"res_blocks.{i}."
+        t = F.relu(F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+        h = h + F.conv2d(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+        i += 1
+    for up in ("up1.0", "up2.0"):
+        h = F.relu(F.pixel_shuffle(F.conv2d(h, sd[up + ".weight"], sd[up + ".bias"], padding=1), 2))
+    return torch.tanh(F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=3))
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

@@ -1,0 +1,91 @@
+"""The CycleGAN super-resolution generator on the MI355X conv core.
+
+Drop-in for ``ResidualBlock`` / ``GeneratorSR`` of /root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-137 (the
+v2 script, CycleGAN_w_v2/CycleGAN2.py:102-150, defines the same network): same constructor arguments, same
+``state_dict`` keys (``conv1.0.*``, ``res_blocks.N.conv{1,2}.*``, ``up{1,2}.0.*``, ``conv_out.*``), NCHW fp32 in and
+out, trainable through autograd.  Every 3x3 convolution — the residual blocks and the two sub-pixel stages, 97 % of
+the FLOPs — runs on the HIP kernels of ``conv_core`` (bf16 operands, fp32 accumulation) with ReLU fused as a
+LeakyReLU of slope 0; the residual trunk is carried in fp32 beside the bf16 copy the next convolution reads.  The two
+7x7 convolutions, PixelShuffle and tanh stay on stock PyTorch-ROCm.
+"""
+import torch
+from torch import Tensor, nn
+import torch.nn.functional as F
+
+from . import conv_core as cc
+
+
+def _need_cuda(x: Tensor, who: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(f"super_resolution_amd.{who} runs on ROCm devices only: move the module and its input to "
+                           "'cuda' (there is no CPU fallback)")
+
+
+def _nchw_to_f32(v: Tensor) -> Tensor:
+    """NCHW fp32 -> the conv core's fp32 layout [N, H, C/4, W, 4]."""
+    N, C, H, W = v.shape
+    return v.view(N, C // 4, 4, H, W).permute(0, 3, 1, 4, 2).contiguous()
+
+
+def _f32_to_blocked(t: Tensor) -> Tensor:
+    """fp32 layout [N, H, C/4, W, 4] -> blocked bf16 [N, H, C/8, W, 8] (what the next convolution reads)."""
+    N, H, Q, W, _ = t.shape
+    return t.view(N, H, Q // 2, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, Q // 2, W, 8).to(torch.bfloat16)
+
+
+class ResidualBlock(nn.Module):
+    """CycleGAN.py:89-100 — ``x + conv2(relu(conv1(x)))``."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        if channels % 8:
+            raise ValueError("channels must be a multiple of 8 (whole 8-channel units)")
+        self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
+
+    def _run(self, xb: Tensor, trunk: Tensor):
+        """(blocked bf16 x, fp32 x) -> the same pair for the block's output."""
+        h = cc.conv3x3(xb, self.conv1.weight, self.conv1.bias, 0.0)              # ReLU fused
+        y = cc.conv3x3(h, self.conv2.weight, self.conv2.bias, 1.0, f32_out=True)
+        trunk = trunk + y
+        return _f32_to_blocked(trunk), trunk
+
+    def forward(self, x: Tensor) -> Tensor:
+        _need_cuda(x, "ResidualBlock")
+        v = x.float()
+        _xb, trunk = self._run(cc.to_blocked(v), _nchw_to_f32(v))
+        return cc.f32_as_nchw(trunk)
+
+
+class GeneratorSR(nn.Module):
+    """CycleGAN.py:103-137 — LR -> HR (x4): 7x7 conv + ReLU, residual blocks, two (3x3 conv to 4x channels,
+    PixelShuffle(2), ReLU) stages, 7x7 conv, tanh."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, num_residual: int = 6, base_channels: int = 64):
+        super().__init__()
+        if base_channels % 8:
+            raise ValueError("base_channels must be a multiple of 8 (whole 8-channel units)")
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, base_channels, kernel_size=7, stride=1, padding=3),
+                                   nn.ReLU(inplace=True))
+        self.res_blocks = nn.Sequential(*[ResidualBlock(base_channels) for _ in range(num_residual)])
+        self.up1 = nn.Sequential(nn.Conv2d(base_channels, base_channels * 4, kernel_size=3, stride=1, padding=1),
+                                 nn.PixelShuffle(2), nn.ReLU(inplace=True))
+        self.up2 = nn.Sequential(nn.Conv2d(base_channels, base_channels * 4, kernel_size=3, stride=1, padding=1),
+                                 nn.PixelShuffle(2), nn.ReLU(inplace=True))
+        self.conv_out = nn.Conv2d(base_channels, out_channels, kernel_size=7, stride=1, padding=3)
+        self.tanh = nn.Tanh()
+
+    def forward(self, x: Tensor) -> Tensor:
+        _need_cuda(x, "GeneratorSR")
+        v = self.conv1(x.float())                                   # 7x7: stock PyTorch-ROCm
+        xb, trunk = cc.to_blocked(v), _nchw_to_f32(v)
+        for block in self.res_blocks:
+            xb, trunk = block._run(xb, trunk)
+        for up in (self.up1, self.up2):
+            conv = up[0]
+            # ReLU commutes with the pixel shuffle: fused into the convolution as slope 0; the shuffle moves bf16
+            y = cc.conv3x3(xb, conv.weight, conv.bias, 0.0)
+            v = F.pixel_shuffle(cc.blocked_as_nchw(y), 2)
+            xb = cc.nchw_as_blocked(v)
+        return self.tanh(self.conv_out(v.float()))

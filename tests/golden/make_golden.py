@@ -8,6 +8,7 @@ text is stored: fixtures hold seeds, inputs, outputs and gradients only.
 
     cd /tmp && python /root/repo/tests/golden/make_golden.py        # all fixtures
     cd /tmp && python /root/repo/tests/golden/make_golden.py g8     # only g8_adversarial_step.npz
+    cd /tmp && python /root/repo/tests/golden/make_golden.py g9     # only g9_cyclegan_sr.npz (+ manifest)
 """
 import importlib.util
 import os
@@ -105,7 +106,38 @@ def make_g8(ref):
             st[f"wsum/{name}"] = np.float64(p.double().sum().item())
     np.savez_compressed(os.path.join(HERE, "g8_adversarial_step.npz"), **st)
 
+def make_g9():
+    # G9: the CycleGAN super-resolution generator (CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-137).  The file imports
+    # torchvision.transforms at top level (used by its dataset class only): an empty stand-in module lets it load;
+    # its training entry point sits behind `if __name__ == "__main__"`.
+    for m in ("torchvision", "torchvision.transforms"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    spec = importlib.util.spec_from_file_location("ref_cyclegan_v1", "/root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(9)
+    net = mod.GeneratorSR(num_residual=3)
+    g = torch.Generator().manual_seed(109)
+    x = (torch.rand(2, 3, 12, 10, generator=g) * 2 - 1).requires_grad_(True)      # the dataset normalises to [-1, 1]
+    r = torch.randn(2, 3, 48, 40, generator=g)
+    out = net(x)
+    (out * r).sum().backward()
+    st = {"seed": 9, "num_residual": 3, "x": x.detach().numpy(), "r": r.numpy(), "out": out.detach().numpy(),
+          "grad_x": x.grad.numpy()}
+    put_grads(st, net, full=("conv1.0.bias", "res_blocks.2.conv2.bias", "conv_out.bias"))
+    weight_sums(st, net)
+    np.savez_compressed(os.path.join(HERE, "g9_cyclegan_sr.npz"), **st)
+    with open(os.path.join(HERE, "g9_cyclegan_sr_manifest.txt"), "w") as f:
+        for k, v in mod.GeneratorSR().state_dict().items():
+            f.write(f"{k} {tuple(v.shape)}\n")
+
+
 def main():
+    if sys.argv[1:] == ["g9"]:
+        torch.set_num_threads(8)
+        make_g9()
+        return
     ref = load_reference()
     torch.set_num_threads(8)
     if sys.argv[1:] == ["g8"]:          # only the newest fixture; the others are unchanged

@@ -96,3 +96,22 @@ def test_vgg_extractor_keys_follow_torchvision_numbering():
 def test_blocked_unit_arithmetic():
     from super_resolution_amd import conv_core as cc
     assert [cc.units_for(c) for c in (1, 3, 8, 9, 16, 17, 64, 512)] == [2, 2, 2, 2, 2, 4, 8, 64]
+
+
+def test_cyclegan_generator_sr_surface():
+    """CycleGAN/CycleGAN_w_v1/CycleGAN.py:103-127: constructor arguments and state_dict keys / shapes of the
+    reference class (manifest written from it); CPU input is refused."""
+    import os
+    from super_resolution_amd.cyclegan import GeneratorSR, ResidualBlock
+    net = GeneratorSR()
+    lines = open(os.path.join(os.path.dirname(__file__), "golden", "g9_cyclegan_sr_manifest.txt")).read().splitlines()
+    want = [(ln.split(" ", 1)[0], ln.split(" ", 1)[1]) for ln in lines]
+    got = [(k, str(tuple(v.shape))) for k, v in net.state_dict().items()]
+    assert got == want
+    assert len(GeneratorSR(num_residual=2, base_channels=32).res_blocks) == 2
+    with pytest.raises(RuntimeError):
+        net(torch.rand(1, 3, 8, 8))
+    with pytest.raises(RuntimeError):
+        ResidualBlock(64)(torch.rand(1, 64, 8, 8))
+    with pytest.raises(ValueError):
+        GeneratorSR(base_channels=12)

@@ -1,5 +1,6 @@
 """CPU: the oracle restatement against vectors produced by the reference classes themselves
 (tests/golden/make_golden.py).  Bit-exact where the same torch ops run in the same order."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -183,3 +184,26 @@ def test_adversarial_iteration_matches_reference_run(golden):
     for name, v in r["state_G"].items():          # parameters after both Adam steps
         ref = float(g[f"wsum/{name}"])
         assert abs(v.double().sum().item() - ref) <= 1e-5 * max(1.0, abs(ref)), name
+
+
+def test_cyclegan_generator_sr_g9(golden):
+    """G9: CycleGAN/CycleGAN_w_v1/CycleGAN.py GeneratorSR(num_residual=3) built under torch.manual_seed(9): the
+    oracle draws the same weights, computes the same output and the same gradients."""
+    g = golden("g9_cyclegan_sr.npz")
+    sd = O.make_generator_sr_state(int(g["seed"]), num_residual=int(g["num_residual"]))
+    for name, v in sd.items():
+        ref = float(g[f"wsum/{name}"])
+        assert abs(v.double().sum().item() - ref) <= 1e-9 * max(1.0, abs(ref)), name
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    out = O.generator_sr_forward(params, x)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=0, atol=2e-6)
+    (out * torch.from_numpy(g["r"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-4, atol=1e-6)
+    for name, p in params.items():
+        ref_abs = float(g[f"gabs/{name}"])
+        assert abs(p.grad.double().abs().sum().item() - ref_abs) <= 1e-4 * ref_abs + 1e-9, name
+    np.testing.assert_allclose(params["conv_out.bias"].grad.numpy(), g["gfull/conv_out.bias"], rtol=1e-4, atol=1e-6)
+    keys = [ln.split(" ", 1)[0] for ln in open(os.path.join(os.path.dirname(__file__), "golden",
+                                                           "g9_cyclegan_sr_manifest.txt")).read().splitlines()]
+    assert keys == list(O.make_generator_sr_state(0).keys())
