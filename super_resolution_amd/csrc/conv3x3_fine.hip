@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     constexpr int WAVES = G::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SR355_FSTAMP(0);
+#ifdef SR355_TRACE
+    const unsigned long long sclk0_ = __builtin_readcyclecounter();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -325,6 +328,10 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     // drain the DMA still in flight (dummy stages) before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SR355_FSTAMP(15);
+#ifdef SR355_TRACE
+    if (a.trace && threadIdx.x == 0)   // shader-clock ticks from the first to the last stamp (clock under load)
+        a.trace[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = __builtin_readcyclecounter() - sclk0_;
+#endif
 #ifdef SR355_TRACE
     if (a.trace && threadIdx.x == 0)
         for (int k = 0; k < 8; ++k) a.trace[(4096 + blockIdx.y * gridDim.x + blockIdx.x) * 16 + k] = st_[k];

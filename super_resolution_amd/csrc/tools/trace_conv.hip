@@ -67,12 +67,13 @@ static int mfma_peak() {
     (void)hipEventCreate(&e1);
     for (int random_data = 0; random_data <= 1; ++random_data)
     for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu)
-        for (int iters : {2000, 20000, 200000}) {
+        for (int iters : {20000, 200000}) {
             const int grid = 256 * wg_per_cu;
-            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk, random_data);
+            auto kern = mfma_peak_kernel<4>;
+            kern<<<grid, 256>>>(out, iters, clk, random_data);
             (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            mfma_peak_kernel<4><<<grid, 256>>>(out, iters, clk, random_data);
+            kern<<<grid, 256>>>(out, iters, clk, random_data);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms = 0;
@@ -110,6 +111,15 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&trace, 2 * max_wg * 16 * 8));
     CK(hipMemset(in, 0x3c, act_bytes));
     CK(hipMemset(w, 0x3b, w_bytes));
+    if (getenv("TRACE_RANDOM")) {   // random bf16 operands in (-2, 2): the data toggling of a real forward
+        std::vector<unsigned short> hb(act_bytes / 2), hw(w_bytes / 2);
+        unsigned long long sd = 88172645463325252ull;
+        auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return sd; };
+        for (auto &v : hb) { const unsigned long long r = rnd(); v = (unsigned short)(((r & 1) << 15) | (0x3f00 + ((r >> 1) & 0xff)) | (((r >> 9) & 1) << 7)); }
+        for (auto &v : hw) { const unsigned long long r = rnd(); v = (unsigned short)(((r & 1) << 15) | (0x3c00 + ((r >> 1) & 0x1ff))); }
+        CK(hipMemcpy(in, hb.data(), act_bytes, hipMemcpyHostToDevice));
+        CK(hipMemcpy(w, hw.data(), w_bytes, hipMemcpyHostToDevice));
+    }
     CK(hipMemset(bias, 0, cout_pad * 4));
     CK(hipMemset(t1, 0, f32_bytes));
     CK(hipMemset(t2, 0, f32_bytes));
@@ -159,6 +169,19 @@ int main(int argc, char **argv) {
         }
     printf("cin_units %d cout %d res %d  N %d H %d W %d: event time %.1f us, %d workgroups, first start -> last end %.2f us\n",
            cin_units, cout, nres, N, H, W, ms * 1e3, nwg, (tend - t0) * 0.01);
+    {   // shader clock under load: ticks (slot 14) over the wall time between the first and the last stamp
+        std::vector<double> mhz;
+        for (int b = 0; b < nwg; ++b)
+            if (t[b * 16 + 14] && t[b * 16 + 15] > t[b * 16]) {
+                mhz.push_back((double)t[b * 16 + 14] / ((t[b * 16 + 15] - t[b * 16]) * 0.01));
+                t[b * 16 + 14] = 0;
+            }
+        if (!mhz.empty()) {
+            std::sort(mhz.begin(), mhz.end());
+            printf("  shader clock during the kernel: median %.0f MHz (p10 %.0f, p90 %.0f)\n", mhz[mhz.size() / 2],
+                   mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10]);
+        }
+    }
     const char *names[16] = {"start", "prologue issued", "stage 0 landed", "tile0 mma done", "tile0 epilogue done",
                              "tile1 mma done", "tile1 epilogue done", "tile2 mma done", "tile2 epi done", "t3 mma",
                              "t3 epi", "t4 mma", "t4 epi", "t5 mma", "t5 epi", "end"};
