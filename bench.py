@@ -53,10 +53,10 @@ def measure_kernels(net, N, H, W, forwards=3):
     outer = trunk.clone()
     P = N * H * W
 
-    def timed(count, *conv):
+    def timed(count, *conv, **kw):
         """Average duration of one launch: the argument record is built once, then the C entry point is
         called back to back on torch's current stream between two HIP events recorded on that stream."""
-        a = ops.conv_args(*conv)
+        a = ops.conv_args(*conv, **kw)
         reps = count * forwards
         ops.launch_conv(a)
         torch.cuda.synchronize()
@@ -84,23 +84,27 @@ def measure_kernels(net, N, H, W, forwards=3):
     rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b,
                  conv_bytes(nf + 4 * gc, nf, P, skips=2, f32_out=True)))
     # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
-    sp = 1 if net.hr_split else 0   # HR-side convs carry the weight rounding residue (2x MFMA work)
+    # HR-side convs as the timed forward runs them: fp16 operands, or bf16 with the weight rounding residue (2x MFMA work)
+    f16 = bool(net.hr_f16)
+    sp = 0 if f16 else (1 if net.hr_split else 0)
+    mode = 3 if f16 else sp          # SR355_PACK_F16 / SR355_SPLIT_*
+    hr = dict(weight_split=sp, f16_in=f16, f16_out=f16)
     wt, bt = ops.pack_weight(net.trunk_conv.weight.detach(), net.trunk_conv.bias.detach(), dt)
-    w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt, sp)
-    wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt, sp)
+    w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt, mode)
+    wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt, mode)
     lr = torch.zeros((N, H, nf // 8, W, 8), dtype=torch.bfloat16, device=dev).normal_()
     h1 = torch.empty((N, 2 * H, nf // 8, 2 * W, 8), dtype=torch.bfloat16, device=dev)
     h2 = torch.empty((N, 4 * H, nf // 8, 4 * W, 8), dtype=torch.bfloat16, device=dev)
     h3 = torch.empty_like(h2)
     out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
     nu = nf // 8
-    ta = timed(1, lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, sp)
+    ta = timed(1, lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, **hr)
     rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta, conv_bytes(nf, nf, 4 * P, P)))
-    tb = timed(1, h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, sp)
+    tb = timed(1, h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, **hr)
     rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb, conv_bytes(nf, nf, 16 * P, 4 * P)))
-    tc = timed(1, h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, sp)
+    tc = timed(1, h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, **hr)
     rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc, conv_bytes(nf, nf, 16 * P)))
-    td = timed(1, h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, sp)
+    td = timed(1, h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, weight_split=sp, f16_in=f16)
     rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td,
                  conv_bytes(nf, net.out_channels, 16 * P, bf16_out=False, nchw_out=net.out_channels)))
     tt = timed(1, buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None)
@@ -331,6 +335,9 @@ def main():
     ap.add_argument("--train-graph", action="store_true",
                     help="also replay the pixel iteration from a captured HIP graph (measured slower than eager issue: "
                          "about 3,000 graph nodes per step)")
+    ap.add_argument("--hr-side", choices=("f16", "split"), default="f16",
+                    help="arithmetic of the four HR-side convs in the timed (no-grad) forward: IEEE fp16 (default of the "
+                         "module, 58.6 dB) or bf16 with a second weight image holding the rounding residue (53.9 dB)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batch parts the forward runs on concurrent HIP streams (0 = library default, 2); "
                          "1 serialises the kernels, which is what a per-kernel profile needs")
@@ -364,7 +371,7 @@ def main():
         os.environ["SR355_STREAMS"] = str(args.streams)      # read once, when the library first runs a forward
     import super_resolution_amd as S
     torch.manual_seed(0)
-    net = S.GeneratorRRDB(precision="bf16").to(dev).eval()
+    net = S.GeneratorRRDB(precision="bf16", hr_f16=args.hr_side == "f16").to(dev).eval()
     B, H, W = args.batch, args.size, args.size
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
@@ -395,7 +402,9 @@ def main():
         "config": {"workload": f"configs[1]: RRDBNet x4 (nf=64, 23 RRDB) bf16 inference, batch {B} of 3x{H}x{W} "
                                f"LR patches per GPU -> 3x{4 * H}x{4 * W}, inputs resident in HBM",
                    "batch_per_gpu": B, "lr_size": [H, W], "parallelism": f"patch-sharded x{world}, no collective",
-                   "streams_per_gpu": args.streams if args.streams > 0 else 2},
+                   "streams_per_gpu": args.streams if args.streams > 0 else 2,
+                   "hr_side": "fp16 (4 of 351 convs, 8 % of the FLOPs; the other 347 in bf16)" if args.hr_side == "f16"
+                              else "bf16 + weight rounding residue"},
         "generator_tflops": round(world * B * H * W * FLOP_PER_LR_PIXEL * args.steps / elapsed / 1e12, 1),
     }
     if rank == 0:

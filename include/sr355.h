@@ -48,8 +48,10 @@ extern "C" {
 #define SR355_SPLIT_NONE 0
 #define SR355_SPLIT_WEIGHT 1
 #define SR355_SPLIT_INPUT 2
+#define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
+                              conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 7
+#define SR355_ABI_VERSION 8
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -112,6 +114,11 @@ typedef struct sr355_conv_args {
     float *out_f32_dev;        /* fp32 trunk [N][H][cout/4][W][4]                           */
     float *out_nchw_dev;       /* [N][cout][H][W] fp32                                     */
     size_t out_nchw_bytes;
+    /* bf16 dtype only: the 16-byte units of the input and of the weights (packed with SR355_PACK_F16,
+     * weight_split = SR355_SPLIT_NONE) hold IEEE fp16 and the fp16 MFMA multiplies them; out_act is
+     * stored as fp16 (for a following f16_in conv).  No counterpart in the reference: a precision
+     * device for the four HR-side convs of the generator's inference forward. */
+    int f16_in, f16_out;
 } sr355_conv_args;
 
 int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
@@ -164,9 +171,14 @@ typedef struct sr355_generator_cfg {
     int in_channels, out_channels, num_features, num_blocks, growth_channels; /* :42 */
     int dtype;
     int trunk_fp32;            /* 1: residual trunk carried in fp32 beside the bf16 copy  */
-    int hr_split;              /* 1 (bf16): SPLIT_INPUT on conv_first and SPLIT_WEIGHT on the
-                                  four HR-side convs (upconv1/2, HR_conv, conv_last)       */
+    int hr_split;              /* bf16 only.  1: SPLIT_INPUT on conv_first and SPLIT_WEIGHT on the
+                                  four HR-side convs (upconv1/2, HR_conv, conv_last).
+                                  SR355_HR_F16 (2), inference only: SPLIT_INPUT on conv_first and
+                                  the four HR-side convs in IEEE fp16 (weights and the activations
+                                  they read: 11 significant bits instead of 8 at the same MFMA rate,
+                                  no second weight image); the training entry points refuse it   */
 } sr355_generator_cfg;
+#define SR355_HR_F16 2
 
 /* Number of 3x3 convs (351 for the default config). */
 int sr355_generator_num_convs(const sr355_generator_cfg *cfg);

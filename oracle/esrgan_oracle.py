@@ -118,10 +118,13 @@ _HR_SIDE = ("upconv1", "upconv2", "HR_conv", "conv_last")
 def _conv(sd: StateDict, name: str, x: torch.Tensor, emulate_bf16, stride: int = 1) -> torch.Tensor:
     """``emulate_bf16``: False = fp32 (the reference); True = every conv rounds weights and input to
     bf16; "hr_split" = as True, except that the HR-side convs keep their weights exact and
-    conv_first keeps weights and input exact (the residue-carrying modes of the HIP path)."""
+    conv_first keeps weights and input exact (the residue-carrying modes of the HIP path); "hr_f16" = as
+    "hr_split", except that the HR-side convs round weights and input to fp16 instead."""
     w, b = sd[name + ".weight"], sd[name + ".bias"]
+    if emulate_bf16 == "hr_f16" and name in _HR_SIDE:
+        return F.conv2d(x.to(torch.float16).float(), w.to(torch.float16).float(), b, stride=stride, padding=1)
     if emulate_bf16:
-        split = emulate_bf16 == "hr_split"
+        split = emulate_bf16 in ("hr_split", "hr_f16")
         if not (split and (name in _HR_SIDE or name == "conv_first")):
             w = _bf16r(w)
         if not (split and name == "conv_first"):

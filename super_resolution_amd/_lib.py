@@ -16,8 +16,10 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
+PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
+HR_F16 = 2       # sr355_generator_cfg.hr_split: HR-side convs in fp16 (inference)
 
 # every symbol include/sr355.h declares
 EXPORTS = (
@@ -54,6 +56,7 @@ class ConvArgs(C.Structure):
         ("out_units", C.c_int), ("out_unit_off", C.c_int),
         ("out_f32_dev", C.c_void_p),
         ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
+        ("f16_in", C.c_int), ("f16_out", C.c_int),
     ]
 
 

@@ -36,6 +36,7 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 struct ConvSpec {
     int cin, cout, split;
     size_t w_off, b_off;  // offsets into the packed blob
+    int f16 = 0;          // weights packed as fp16, input read as fp16 (HR side of an inference-only pack)
 };
 
 static bool cfg_ok(const sr355_generator_cfg *c) {
@@ -62,7 +63,8 @@ static std::vector<ConvSpec> conv_specs(const sr355_generator_cfg &c, size_t *to
     std::vector<ConvSpec> v;
     const int nf = c.num_features, gc = c.growth_channels;
     const bool split = c.hr_split && c.dtype == SR355_DTYPE_BF16;
-    const int hs = split ? SR355_SPLIT_WEIGHT : SR355_SPLIT_NONE;
+    const bool hr16 = c.hr_split == SR355_HR_F16 && c.dtype == SR355_DTYPE_BF16;
+    const int hs = (split && !hr16) ? SR355_SPLIT_WEIGHT : SR355_SPLIT_NONE;
     v.push_back({c.in_channels, nf, split ? SR355_SPLIT_INPUT : SR355_SPLIT_NONE, 0, 0});
     for (int b = 0; b < c.num_blocks; ++b)
         for (int r = 0; r < 3; ++r)
@@ -70,6 +72,8 @@ static std::vector<ConvSpec> conv_specs(const sr355_generator_cfg &c, size_t *to
     v.push_back({nf, nf, SR355_SPLIT_NONE, 0, 0});              // trunk_conv
     for (int i = 0; i < 3; ++i) v.push_back({nf, nf, hs, 0, 0});  // upconv1, upconv2, HR_conv
     v.push_back({nf, c.out_channels, hs, 0, 0});                 // conv_last
+    if (hr16)
+        for (size_t i = v.size() - 4; i < v.size(); ++i) v[i].f16 = 1;
     size_t off = 0;
     for (auto &s : v) {
         s.w_off = off;
@@ -161,9 +165,14 @@ static bool split_ok(int dtype, int split) {
     return split == SR355_SPLIT_NONE ||
            (dtype == SR355_DTYPE_BF16 && (split == SR355_SPLIT_WEIGHT || split == SR355_SPLIT_INPUT));
 }
+// sr355_pack_weight also takes SR355_PACK_F16 (one image, fp16 values)
+static bool pack_mode_ok(int dtype, int split) {
+    return split_ok(dtype, split) || (dtype == SR355_DTYPE_BF16 && split == SR355_PACK_F16);
+}
 
 size_t sr355_packed_weight_bytes(int cout, int cin, int dtype, int split) {
-    if (unit_channels(dtype) < 0 || cout < 1 || cin < 1 || !split_ok(dtype, split)) return 0;
+    if (unit_channels(dtype) < 0 || cout < 1 || cin < 1 || !pack_mode_ok(dtype, split)) return 0;
+    if (split == SR355_PACK_F16) split = SR355_SPLIT_NONE;
     return (size_t)packed_units_for(cin, dtype, split) * 9 * cout_pad_for(cout) * 16;
 }
 
@@ -269,6 +278,12 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     a.out_act = (unsigned char *)p->out_act_dev;
     a.out_f32 = p->out_f32_dev;
     a.out_nchw = p->out_nchw_dev;
+    if ((p->f16_in || p->f16_out) && (p->dtype != SR355_DTYPE_BF16 || (p->f16_in && p->weight_split != SR355_SPLIT_NONE))) {
+        set_error("conv3x3_fwd: f16_in / f16_out exist on the bf16 path only, f16_in with unsplit weights");
+        return SR355_ERR_INVALID;
+    }
+    a.f16_in = p->f16_in ? 1 : 0;
+    a.f16_out = p->f16_out ? 1 : 0;
     a.res1 = p->res1_dev;
     a.res2 = p->res2_dev;
     a.res1_scale = p->res1_scale;
@@ -408,7 +423,7 @@ int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_p
             return SR355_ERR_INVALID;
         }
         jobs[i] = PackJob{w_ptrs[i], b_ptrs[i], base + specs[i].w_off, (float *)(base + specs[i].b_off), specs[i].cout,
-                          specs[i].cin, specs[i].split};
+                          specs[i].cin, specs[i].split, specs[i].f16};
     }
     return launch_pack_weight_batch(jobs.data(), (int)jobs.size(), cfg->dtype, (hipStream_t)stream);
 }
@@ -553,6 +568,9 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             a.cout_real = sp.cout;
             a.cout_pad = cout_pad_for(sp.cout);
             a.f32_units = sp.cout / 4;
+            a.f16_in = sp.f16;
+            // a blocked output that the next conv reads as fp16: every conv in front of an fp16 one
+            a.f16_out = (out_act && ci < specs.size() && specs[ci].f16) ? 1 : 0;
             const int rc_ = launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, part_stream[p]);
             if (rc_) return rc_;
         }
@@ -728,6 +746,10 @@ static bool train_ok(const sr355_generator_cfg *cfg) {
     if (!cfg_ok(cfg)) return false;
     if (cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features > 64 || cfg->growth_channels > 64) {
         set_error("training path: bf16 kernels with num_features, growth_channels <= 64 only");
+        return false;
+    }
+    if (cfg->hr_split == SR355_HR_F16) {
+        set_error("training path: the fp16 HR side (hr_split = 2) is an inference mode; train with hr_split 0 or 1");
         return false;
     }
     return true;

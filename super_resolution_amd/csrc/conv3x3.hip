@@ -31,6 +31,7 @@
 namespace sr355 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -39,9 +40,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <typename T> struct Frag;
 template <> struct Frag<__bf16> { typedef bf16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<_Float16> { typedef f16x8 type; };
 
 __device__ __forceinline__ void mma(f32x16 &c, const bf16x8 &a, const bf16x8 &b) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16 &c, const f16x8 &a, const f16x8 &b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 // One 16-byte unit pair (lane half h holds unit 2s+h) = 8 fp32 channels = four K=2 steps; step t
 // multiplies element t of both operands, i.e. channel 4*(2s+h)+t on lane half h.
@@ -269,7 +274,7 @@ static int launch_nb(const ConvArgs &a, hipStream_t stream) {
 
 // bf16 at small tile counts: with 4-row tiles a stage is 9*MB MFMAs per wave against one global-load latency, so the
 // K loop is latency-bound; stages of four units (32 channels) halve the number of those latencies.
-template <int MB>
+template <int MB, typename T16 = __bf16>
 static int launch_bf16(const ConvArgs &a, int cin_units, int weight_split, hipStream_t stream) {
     const long long tx = (a.W + 31) / 32;
     const long long cblk = a.cout_pad / (32 * MB);
@@ -278,9 +283,9 @@ static int launch_bf16(const ConvArgs &a, int cin_units, int weight_split, hipSt
         ConvArgs b = a;
         b.n_real_stages = cin_units / 4;
         b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
-        return launch_inst<__bf16, MB, 1, 4>(b, stream);
+        return launch_inst<T16, MB, 1, 4>(b, stream);
     }
-    return launch_nb<__bf16, MB, 2>(a, stream);
+    return launch_nb<T16, MB, 2>(a, stream);
 }
 
 int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split, hipStream_t stream) {
@@ -311,6 +316,9 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
         const long long blocks4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.cout_pad / 64);
         if (split_knob && blocks4 < 256) wide = false;
     }
+    if (dtype == SR355_DTYPE_BF16 && a.f16_in)      // the same 16-byte units holding IEEE fp16
+        return wide ? launch_bf16<2, _Float16>(b, cin_units, weight_split, stream)
+                    : launch_bf16<1, _Float16>(b, cin_units, weight_split, stream);
     if (dtype == SR355_DTYPE_BF16)
         return wide ? launch_bf16<2>(b, cin_units, weight_split, stream) : launch_bf16<1>(b, cin_units, weight_split, stream);
     if (dtype == SR355_DTYPE_F32)

@@ -38,8 +38,18 @@ extern unsigned long long *g_conv_trace;
 
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
+
+// one MFMA on two 16-byte fragments: bf16, or the same bits read as IEEE fp16
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(const bf16x8 &w, const bf16x8 &x, const f32x16 &c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, c, 0, 0, 0);
+}
 
 constexpr int TWP = 34;          // tile width 32 + halo
 constexpr int RSU = 2;           // units per stage
@@ -72,7 +82,7 @@ struct FineGeo {
 };
 }  // namespace
 
-template <int MB, int NB, int R, int WPS>
+template <int MB, int NB, int R, int WPS, bool F16>
 __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     typedef FineGeo<MB, NB, R> G;
     constexpr int WAVES = G::WAVES;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
                 const int nb = rho - ky;                                                              \
                 if (nb >= 0 && nb < NB) {                                                             \
                     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                 \
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[ky][mb], XF[rho], acc[mb][nb], 0, 0, 0); \
+                        acc[mb][nb] = mma16<F16>(WF[ky][mb], XF[rho], acc[mb][nb]);                   \
                 }                                                                                     \
             }                                                                                         \
     }
@@ -345,13 +355,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 #undef SR355_INTERLEAVE
 }
 
-template <int MB, int NB, int R, int WPS = 2>
-static int launch_fine_inst(const ConvArgs &a0, hipStream_t stream) {
+template <int MB, int NB, int R, int WPS, bool F16>
+static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     typedef FineGeo<MB, NB, R> G;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
-    auto kern = conv3x3_fine<MB, NB, R, WPS>;
+    auto kern = conv3x3_fine<MB, NB, R, WPS, F16>;
     static bool attr_done[64] = {};
     static int n_cu[64] = {};
     int dev = 0;
@@ -381,6 +391,12 @@ static int launch_fine_inst(const ConvArgs &a0, hipStream_t stream) {
     dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots), a.cout_pad / G::CO, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, stream, a);
     return check_hip(hipGetLastError(), "conv3x3 fine launch");
+}
+
+template <int MB, int NB, int R, int WPS = 2>
+static int launch_fine_inst(const ConvArgs &a, hipStream_t stream) {
+    return a.f16_in ? launch_fine_typed<MB, NB, R, WPS, true>(a, stream)
+                    : launch_fine_typed<MB, NB, R, WPS, false>(a, stream);
 }
 
 // Entry: bf16 only, cin_units even, cout_pad 32 or 64; `a` carries n_stages / n_real_stages / debug.

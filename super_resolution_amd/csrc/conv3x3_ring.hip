@@ -332,7 +332,7 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
     const bool wide = (a.cout_pad % 64) == 0;
     // 9 (default): the branch-free, MFMA-interleaved stage body of conv3x3_fine.hip; 5: this file's phase-ordered
     // body (two workgroups per CU; one stage in flight for the 64-channel convs, two for the 32-channel ones)
-    if (var != 5) return launch_conv3x3_fine(b, stream);
+    if (var != 5 || a.f16_in) return launch_conv3x3_fine(b, stream);
     return wide ? launch_ring_inst<2, 2, 4, 2>(b, stream) : launch_ring_inst<1, 2, 4, 3>(b, stream);
 }
 

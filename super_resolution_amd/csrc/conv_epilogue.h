@@ -11,6 +11,7 @@
 namespace sr355 {
 
 typedef __attribute__((ext_vector_type(4))) __bf16 epi_bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 epi_f16x4;
 
 template <typename T>
 __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)[4], int n, int y, int x, int c0,
@@ -54,12 +55,21 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
     if (a.out_act) {
         if constexpr (sizeof(T) == 2) {
             const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 3)) * W + x) * 16 + h * 8;
-            epi_bf16x4 pk;
-            pk[0] = (__bf16)v[0];
-            pk[1] = (__bf16)v[1];
-            pk[2] = (__bf16)v[2];
-            pk[3] = (__bf16)v[3];
-            *reinterpret_cast<epi_bf16x4 *>(a.out_act + o) = pk;
+            if (a.f16_out) {
+                epi_f16x4 pk;
+                pk[0] = (_Float16)v[0];
+                pk[1] = (_Float16)v[1];
+                pk[2] = (_Float16)v[2];
+                pk[3] = (_Float16)v[3];
+                *reinterpret_cast<epi_f16x4 *>(a.out_act + o) = pk;
+            } else {
+                epi_bf16x4 pk;
+                pk[0] = (__bf16)v[0];
+                pk[1] = (__bf16)v[1];
+                pk[2] = (__bf16)v[2];
+                pk[3] = (__bf16)v[3];
+                *reinterpret_cast<epi_bf16x4 *>(a.out_act + o) = pk;
+            }
         } else {
             const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 2)) * W + x) * 16;
             *reinterpret_cast<float4 *>(a.out_act + o) = make_float4(v[0], v[1], v[2], v[3]);

@@ -11,6 +11,7 @@ namespace sr355 {
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 
 // One thread per (n, y, unit, x): gathers CPU channels from NCHW and writes one 16-byte unit.
 // split != 0 (bf16): channels [0,C) hold bf16(x) and channels [C,2C) the rounding residue
@@ -129,6 +130,12 @@ __global__ void pack_weight_batch_kernel(const PackJobTable t) {
     const int split = sizeof(T) == 2 ? j.split : 0;   // only the bf16 path carries rounding residues
     const int real = split == SR355_SPLIT_INPUT ? 2 * j.cin : j.cin;
     const int U = ((real + CPU - 1) / CPU + 1) / 2 * 2;   // whole stages of two units
+    if constexpr (sizeof(T) == 2) {
+        if (j.f16) {
+            pack_weight_body<_Float16>(j.w, j.bias, (_Float16 *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, 0);
+            return;
+        }
+    }
     pack_weight_body<T>(j.w, j.bias, (T *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, split);
 }
 
@@ -175,6 +182,12 @@ int launch_blocked_to_nchw(const void *src, int src_units, int unit_off, int dty
 
 int launch_pack_weight(const float *w, const float *bias, int cout, int cin, int dtype, int split,
                        void *wp, float *bp, hipStream_t stream) {
+    if (dtype == SR355_DTYPE_BF16 && split == SR355_PACK_F16) {
+        const int cu16 = real_units_for(cin, dtype, 0), cp16 = cout_pad_for(cout);
+        hipLaunchKernelGGL(pack_weight_kernel<_Float16>, dim3(grid_for((size_t)cu16 * 9 * cp16)), dim3(256), 0, stream,
+                           w, bias, (_Float16 *)wp, bp, cout, cin, cu16, cp16, 0);
+        return check_hip(hipGetLastError(), "pack_weight launch");
+    }
     const int cu = real_units_for(cin, dtype, split), cp = cout_pad_for(cout);
     const size_t total = (size_t)packed_units_for(cin, dtype, split) * 9 * cp;
     if (dtype == SR355_DTYPE_BF16)

@@ -17,6 +17,8 @@ struct ConvArgs {
     unsigned char *out_act;      // blocked, may be null
     float *out_f32;              // fp32 trunk [N][H][f32_units][W][4], may be null
     float *out_nchw;             // [N][cout_real][H][W], may be null
+    int f16_in;                  // bf16 path only: input and weights hold IEEE fp16 (same 16-byte units, f16 MFMA)
+    int f16_out;                 // bf16 path only: out_act is stored as fp16 (it feeds an f16_in conv)
     unsigned char *out_u8;       // uint8 image [N][H][W][cout_real] = trunc(255 * clamp(v, 0, 1)), may be null
     const float *res1;           // fp32 trunk, may be null
     const float *res2;           // fp32 trunk, may be null
@@ -71,6 +73,7 @@ struct PackJob {      // one launch_pack_weight call
     void *wp;
     float *bp;
     int cout, cin, split;
+    int f16;              // bf16 path: store IEEE fp16 instead of bf16 (no rounding residue)
 };
 struct PackTJob {     // one launch_pack_weight_t call
     const float *w;

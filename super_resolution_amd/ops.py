@@ -106,7 +106,7 @@ def pack_weight(w: Tensor, bias: Tensor, dtype: int, split: int = 0) -> Tuple[Te
 def _(w, bias, dtype, split=0):
     cout, cin = w.shape[0], w.shape[1]
     cpu = UNIT_CHANNELS[dtype]
-    cu = (((2 * cin if split == 2 else cin) + cpu - 1) // cpu + 1) // 2 * 2 * (2 if split else 1)
+    cu = (((2 * cin if split == 2 else cin) + cpu - 1) // cpu + 1) // 2 * 2 * (2 if split in (1, 2) else 1)
     cp = (cout + 31) // 32 * 32
     return (w.new_empty(cu * 9 * cp * 16, dtype=torch.uint8), w.new_empty(cp, dtype=torch.float32))
 
@@ -117,7 +117,8 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
               out_act: Optional[Tensor], out_unit_off: int,
               out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
               mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
-              res1_weight: float = 1.0, res2_weight: float = 1.0) -> ConvArgs:
+              res1_weight: float = 1.0, res2_weight: float = 1.0, f16_in: bool = False,
+              f16_out: bool = False) -> ConvArgs:
     """The sr355_conv_args record for one conv launch (the tensors must outlive its use)."""
     _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw, mask)
     a = ConvArgs()
@@ -152,6 +153,7 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
     a.out_unit_off = int(out_unit_off)
     a.out_f32_dev = _ptr(out_f32)
     a.out_nchw_dev, a.out_nchw_bytes = _ptr(out_nchw), _nbytes(out_nchw)
+    a.f16_in, a.f16_out = int(bool(f16_in)), int(bool(f16_out))
     return a
 
 

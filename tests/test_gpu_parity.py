@@ -310,7 +310,14 @@ def test_generator_call_site_contract():
         d = net(x)
     assert (d - a - 0.25).abs().max().item() < 1e-5
     e = net(x)                                    # grad mode + trainable parameters: recorded for backward
-    assert e.requires_grad and torch.equal(e.detach(), d)
+    # recorded forwards keep the HR side in bf16 (+ weight residue), no-grad ones run it in fp16: same function,
+    # different rounding
+    assert e.requires_grad and (e.detach() - d).abs().max().item() < 5e-3
+    same = load_net(S.GeneratorRRDB(num_blocks=1, hr_f16=False), sd)
+    with torch.no_grad():
+        same.conv_last.bias += 0.25
+        assert torch.equal(same(x), same(x.clone().requires_grad_(False)))
+    assert torch.equal(same(x).detach(), torch.no_grad()(same)(x))     # hr_f16=False: one arithmetic in both modes
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -375,19 +382,25 @@ def test_config2_size_properties():
     assert clamped >= 50.0 and unclamped >= 50.0   # the unclamped figure is the binding one here
 
 
-def test_hr_split_is_what_clears_the_gate_with_margin():
-    """Same weights and input with and without the residue-carrying convs."""
+def test_hr_side_modes_clear_the_gate_with_margin():
+    """Same weights and input: plain bf16, the residue-carrying HR-side convs (what recorded forwards use), and
+    the fp16 HR side (what no-grad forwards use by default).  The oracle's emulation of each mode predicts the
+    measured figure."""
     sd = O.center_outputs(O.make_generator_state(0))
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(1234))
     with torch.no_grad():
         ref = O.generator_forward(sd, x)
-        res = {}
-        for flag in (False, True):
-            net = load_net(S.GeneratorRRDB(hr_split=flag), sd)
-            res[flag] = O.psnr(net(x.to(DEV)).cpu(), ref)
-    print(f"unclamped PSNR vs fp32: plain bf16 {res[False]:.2f} dB, hr_split {res[True]:.2f} dB")
-    assert res[True] >= 52.0
-    assert res[True] > res[False] + 2.0
+        res, emu = {}, {}
+        for name, kw, mode in (("plain", dict(hr_split=False, hr_f16=False), True),
+                               ("hr_split", dict(hr_split=True, hr_f16=False), "hr_split"),
+                               ("hr_f16", dict(hr_split=True, hr_f16=True), "hr_f16")):
+            net = load_net(S.GeneratorRRDB(**kw), sd)
+            res[name] = O.psnr(net(x.to(DEV)).cpu(), ref)
+            emu[name] = O.psnr(O.generator_forward(sd, x, mode), ref)
+    print("unclamped PSNR vs fp32: " + ", ".join(f"{k} {res[k]:.2f} dB (emulated {emu[k]:.2f})" for k in res))
+    assert res["hr_split"] >= 52.0 and res["hr_split"] > res["plain"] + 2.0
+    assert res["hr_f16"] >= 56.0 and res["hr_f16"] > res["hr_split"] + 2.0
+    assert all(abs(res[k] - emu[k]) < 1.0 for k in res)
 
 
 def test_config4_large_odd_image_full_and_banded():
