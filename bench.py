@@ -77,18 +77,25 @@ def measure_kernels(net, N, H, W, forwards=3):
                      conv_bytes(nf + k * gc, gc, P)))
     wp, bp = packed[4]
     cu = (nf + 4 * gc) // 8
-    t5 = timed(2 * nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None)
-    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5,
-                 conv_bytes(nf + 4 * gc, nf, P, skips=1, f32_out=True)))
-    t5b = timed(nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None)
-    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b,
-                 conv_bytes(nf + 4 * gc, nf, P, skips=2, f32_out=True)))
+    if net.dense_skip_fp32:          # an fp32 carrier for every skip
+        t5 = timed(2 * nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, None, 0.0, nxt, 0, trunk, None)
+        b5 = conv_bytes(nf + 4 * gc, nf, P, skips=1, f32_out=True)
+        t5b = timed(nb, buf, cu, wp, bp, nf, 1.0, 0, trunk, 0.2, outer, 0.2, nxt, 0, outer, None)
+        b5b = conv_bytes(nf + 4 * gc, nf, P, skips=2, f32_out=True)
+    else:                            # dense-block skips read the bf16 activations; fp32 carrier for the RRDB skip only
+        t5 = timed(2 * nb, buf, cu, wp, bp, nf, 1.0, 0, None, 0.2, None, 0.0, nxt, 0, None, None, res_act=buf)
+        b5 = conv_bytes(nf + 4 * gc, nf, P, bf16_skips=1)
+        t5b = timed(nb, buf, cu, wp, bp, nf, 1.0, 0, None, 0.2, outer, 0.2, nxt, 0, outer, None, res_act=buf)
+        b5b = conv_bytes(nf + 4 * gc, nf, P, skips=1, f32_out=True, bf16_skips=1)
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +skip", 2 * nb, conv_flops(nf + 4 * gc, nf, P), t5, b5))
+    rows.append(("MB2", f"conv5 {nf + 4 * gc}->{nf} +2 skips", nb, conv_flops(nf + 4 * gc, nf, P), t5b, b5b))
     # HR side (64 -> 64 at 2x / 4x resolution, 64 -> 3 at 4x)
     # HR-side convs as the timed forward runs them: fp16 operands, or bf16 with the weight rounding residue (2x MFMA work)
     f16 = bool(net.hr_f16)
     sp = 0 if f16 else (1 if net.hr_split else 0)
     mode = 3 if f16 else sp          # SR355_PACK_F16 / SR355_SPLIT_*
     hr = dict(weight_split=sp, f16_in=f16, f16_out=f16)
+    hs1, hs2 = ("MB1f16", "MB2f16") if f16 else ("MB1", "MB2")     # the fp16 instantiations are kernels of their own
     wt, bt = ops.pack_weight(net.trunk_conv.weight.detach(), net.trunk_conv.bias.detach(), dt)
     w64, b64 = ops.pack_weight(net.HR_conv.weight.detach(), net.HR_conv.bias.detach(), dt, mode)
     wl, bl = ops.pack_weight(net.conv_last.weight.detach(), net.conv_last.bias.detach(), dt, mode)
@@ -99,31 +106,32 @@ def measure_kernels(net, N, H, W, forwards=3):
     out = torch.empty((N, net.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=dev)
     nu = nf // 8
     ta = timed(1, lr, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h1, 0, None, None, **hr)
-    rows.append(("MB2", "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta, conv_bytes(nf, nf, 4 * P, P)))
+    rows.append((hs2, "upconv1 (x2 fused)", 1, conv_flops(nf, nf, 4 * P), ta, conv_bytes(nf, nf, 4 * P, P)))
     tb = timed(1, h1, nu, w64, b64, nf, 0.2, 1, None, 0.0, None, 0.0, h2, 0, None, None, **hr)
-    rows.append(("MB2", "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb, conv_bytes(nf, nf, 16 * P, 4 * P)))
+    rows.append((hs2, "upconv2 (x2 fused)", 1, conv_flops(nf, nf, 16 * P), tb, conv_bytes(nf, nf, 16 * P, 4 * P)))
     tc = timed(1, h2, nu, w64, b64, nf, 0.2, 0, None, 0.0, None, 0.0, h3, 0, None, None, **hr)
-    rows.append(("MB2", "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc, conv_bytes(nf, nf, 16 * P)))
+    rows.append((hs2, "HR_conv", 1, conv_flops(nf, nf, 16 * P), tc, conv_bytes(nf, nf, 16 * P)))
     td = timed(1, h3, nu, wl, bl, net.out_channels, 1.0, 0, None, 0.0, None, 0.0, None, 0, None, out, weight_split=sp, f16_in=f16)
-    rows.append(("MB1", "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td,
+    rows.append((hs1, "conv_last -> NCHW", 1, conv_flops(nf, net.out_channels, 16 * P), td,
                  conv_bytes(nf, net.out_channels, 16 * P, bf16_out=False, nchw_out=net.out_channels)))
     tt = timed(1, buf, nu, wt, bt, nf, 1.0, 0, trunk, 1.0, None, 0.0, lr, 0, None, None)
     rows.append(("MB2", "trunk_conv +skip", 1, conv_flops(nf, nf, P), tt, conv_bytes(nf, nf, P, skips=1)))
     return rows
 
 
-def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=True, nchw_out=0):
+def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=True, nchw_out=0, bf16_skips=0):
     """Algorithmic HBM bytes of one launch: bf16 input read once, bf16 output, fp32 skip reads / carrier write,
-    fp32 NCHW image (weights, a few hundred KB, not counted)."""
+    skips read from bf16 activations, fp32 NCHW image (weights, a few hundred KB, not counted)."""
     p_in = p_out if p_in is None else p_in
     return (2 * cin * p_in + (2 * cout * p_out if bf16_out else 0) + 4 * cout * p_out * skips +
+            2 * cout * p_out * bf16_skips +
             (4 * cout * p_out if f32_out else 0) + 4 * nchw_out * p_out)
 
 
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -148,13 +156,15 @@ def roofline_from(rows):
         out[sym] = {"launches_per_forward": cnt, "avg_launch_us": sec / cnt * 1e6, "flop_per_launch": fl / cnt,
                     "achieved": fl / sec / 1e12, "time_s": sec, "bytes_per_launch": nbytes / cnt}
     dom = max(out, key=lambda s: out[s]["time_s"])
-    names = {"MB1": "conv3x3_fine<MB=1,NB=4,R=2> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2> (Cout=64)"}
+    names = {"MB1": "conv3x3_fine<MB=1,NB=4,R=2,bf16> (Cout<=32)", "MB2": "conv3x3_fine<MB=2,NB=2,R=2,bf16> (Cout=64)",
+             "MB1f16": "conv3x3_fine<MB=1,NB=4,R=2,fp16> (conv_last)", "MB2f16": "conv3x3_fine<MB=2,NB=2,R=2,fp16> (HR side)"}
     d = out[dom]
-    symbols = {"MB1": "conv3x3_fine<1, 4, 2, 2>", "MB2": "conv3x3_fine<2, 2, 2, 2>"}
+    symbols = {"MB1": "conv3x3_fine<1, 4, 2, 2, false>", "MB2": "conv3x3_fine<2, 2, 2, 2, false>",
+               "MB1f16": "conv3x3_fine<1, 4, 2, 2, true>", "MB2f16": "conv3x3_fine<2, 2, 2, 2, true>"}
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r01f_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
+            "traffic_source": "profiles/r01g_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
                               "of this command with --streams 1)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),
@@ -162,7 +172,9 @@ def roofline_from(rows):
                    "one stream between two HIP events; the timed forwards themselves run two half-batches on two "
                    "streams, where launches overlap and a per-launch duration is not a kernel rate"}
     other = {names[s]: {"achieved": round(v["achieved"], 2), "frac": round(v["achieved"] / PEAK_BF16_TFLOPS, 4),
-                        "avg_launch_us": round(v["avg_launch_us"], 2)} for s, v in out.items() if s != dom}
+                        "avg_launch_us": round(v["avg_launch_us"], 2), "launches_per_forward": v["launches_per_forward"],
+                        "traffic": measured_traffic(symbols[s]),
+                        "algorithmic_bytes_per_launch": round(v["bytes_per_launch"])} for s, v in out.items() if s != dom}
     per_shape = [{"kernel": sym, "shape": name, "us": round(sec * 1e6, 2), "tflops": round(fl / sec / 1e12, 1)}
                  for sym, name, _c, fl, sec, _b in rows]
     return roof, other, per_shape
@@ -338,6 +350,8 @@ def main():
     ap.add_argument("--hr-side", choices=("f16", "split"), default="f16",
                     help="arithmetic of the four HR-side convs in the timed (no-grad) forward: IEEE fp16 (default of the "
                          "module, 58.6 dB) or bf16 with a second weight image holding the rounding residue (53.9 dB)")
+    ap.add_argument("--dense-skip-fp32", action="store_true",
+                    help="keep an fp32 carrier for the dense-block skips too (58.6 dB instead of 55.6 dB, more epilogue bytes)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batch parts the forward runs on concurrent HIP streams (0 = library default, 2); "
                          "1 serialises the kernels, which is what a per-kernel profile needs")
@@ -371,7 +385,8 @@ def main():
         os.environ["SR355_STREAMS"] = str(args.streams)      # read once, when the library first runs a forward
     import super_resolution_amd as S
     torch.manual_seed(0)
-    net = S.GeneratorRRDB(precision="bf16", hr_f16=args.hr_side == "f16").to(dev).eval()
+    net = S.GeneratorRRDB(precision="bf16", hr_f16=args.hr_side == "f16",
+                          dense_skip_fp32=args.dense_skip_fp32).to(dev).eval()
     B, H, W = args.batch, args.size, args.size
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
 
@@ -404,7 +419,9 @@ def main():
                    "batch_per_gpu": B, "lr_size": [H, W], "parallelism": f"patch-sharded x{world}, no collective",
                    "streams_per_gpu": args.streams if args.streams > 0 else 2,
                    "hr_side": "fp16 (4 of 351 convs, 8 % of the FLOPs; the other 347 in bf16)" if args.hr_side == "f16"
-                              else "bf16 + weight rounding residue"},
+                              else "bf16 + weight rounding residue",
+                   "skip_carriers": "fp32 for every skip" if args.dense_skip_fp32
+                                    else "fp32 for the RRDB and global skips, bf16 activations for the dense-block skips"},
         "generator_tflops": round(world * B * H * W * FLOP_PER_LR_PIXEL * args.steps / elapsed / 1e12, 1),
     }
     if rank == 0:

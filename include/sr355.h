@@ -119,6 +119,12 @@ typedef struct sr355_conv_args {
      * stored as fp16 (for a following f16_in conv).  No counterpart in the reference: a precision
      * device for the four HR-side convs of the generator's inference forward. */
     int f16_in, f16_out;
+    /* bf16 dtype only: the first residual read from blocked bf16 activations (channels [0, cout) of a buffer with
+     * res_act_units units per pixel and the output's N, H, W) instead of the fp32 tensor res1_dev, with the same
+     * weights: v = res1_weight*res_act + res1_scale*v.  This is how a dense-block skip x + 0.2*conv5(...)
+     * (esrgan_model.py:24) runs without an fp32 carrier.  Exclusive with res1_dev. */
+    const void *res_act_dev; size_t res_act_bytes;
+    int res_act_units;
 } sr355_conv_args;
 
 int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
@@ -170,7 +176,11 @@ int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
 typedef struct sr355_generator_cfg {
     int in_channels, out_channels, num_features, num_blocks, growth_channels; /* :42 */
     int dtype;
-    int trunk_fp32;            /* 1: residual trunk carried in fp32 beside the bf16 copy  */
+    int trunk_fp32;            /* 1: every skip (dense block, RRDB, global) adds onto an fp32 carrier kept
+                                  beside the bf16 activations.  SR355_TRUNK_RRDB (2), bf16 inference only:
+                                  the dense-block skips read the bf16 activations themselves and only the
+                                  RRDB and global skips keep fp32 carriers (41 % fewer epilogue bytes per
+                                  RRDB for about 3 dB of PSNR)                                             */
     int hr_split;              /* bf16 only.  1: SPLIT_INPUT on conv_first and SPLIT_WEIGHT on the
                                   four HR-side convs (upconv1/2, HR_conv, conv_last).
                                   SR355_HR_F16 (2), inference only: SPLIT_INPUT on conv_first and
@@ -179,6 +189,7 @@ typedef struct sr355_generator_cfg {
                                   no second weight image); the training entry points refuse it   */
 } sr355_generator_cfg;
 #define SR355_HR_F16 2
+#define SR355_TRUNK_RRDB 2
 
 /* Number of 3x3 convs (351 for the default config). */
 int sr355_generator_num_convs(const sr355_generator_cfg *cfg);

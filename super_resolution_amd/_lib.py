@@ -19,6 +19,7 @@ DTYPE_F32 = 1
 ABI_VERSION = 8
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
+TRUNK_RRDB = 2   # sr355_generator_cfg.trunk_fp32: fp32 carriers for the RRDB / global skips only (inference)
 HR_F16 = 2       # sr355_generator_cfg.hr_split: HR-side convs in fp16 (inference)
 
 # every symbol include/sr355.h declares
@@ -57,6 +58,7 @@ class ConvArgs(C.Structure):
         ("out_f32_dev", C.c_void_p),
         ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
         ("f16_in", C.c_int), ("f16_out", C.c_int),
+        ("res_act_dev", C.c_void_p), ("res_act_bytes", C.c_size_t), ("res_act_units", C.c_int),
     ]
 
 

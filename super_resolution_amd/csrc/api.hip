@@ -284,6 +284,17 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     }
     a.f16_in = p->f16_in ? 1 : 0;
     a.f16_out = p->f16_out ? 1 : 0;
+    if (p->res_act_dev) {
+        const size_t need = (size_t)p->N * p->H * p->W * p->res_act_units * 16;
+        if (p->dtype != SR355_DTYPE_BF16 || p->res1_dev || !aligned16(p->res_act_dev) ||
+            p->res_act_units * 8 < p->cout || p->res_act_bytes < need) {
+            set_error("conv3x3_fwd: res_act needs the bf16 path, no res1, >= cout channels and %zu bytes (got %zu)", need,
+                      p->res_act_bytes);
+            return SR355_ERR_INVALID;
+        }
+        a.res_act = (const unsigned char *)p->res_act_dev;
+        a.res_act_units = p->res_act_units;
+    }
     a.res1 = p->res1_dev;
     a.res2 = p->res2_dev;
     a.res1_scale = p->res1_scale;
@@ -507,6 +518,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     const int nf = cfg->num_features, gc = cfg->growth_channels;
     float *T = fb.T, *R = fb.R, *F = fb.F;
     const int in_split = specs[0].split == SR355_SPLIT_INPUT;
+    const bool rrdb_only = cfg->trunk_fp32 == SR355_TRUNK_RRDB && dtype == SR355_DTYPE_BF16;
     int rc = in_u8 ? launch_u8hwc_to_blocked(in_u8, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units, in_split,
                                              stream)
                    : launch_nchw_to_blocked(in_nchw, N, cfg->in_channels, H, W, dtype, fb.x0, ws.in_units, in_split,
@@ -538,7 +550,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     auto conv = [&](const unsigned char *in, int in_units, int cin_units, int h, int w, int ups,
                     unsigned char *out_act, int out_units, int out_off, float slope, const float *res1, float s1,
                     const float *res2, float s2, float *out_f32, float *out_nc,
-                    unsigned char *out_img = nullptr) -> int {
+                    unsigned char *out_img = nullptr, const unsigned char *res_act = nullptr) -> int {
         const ConvSpec &sp = specs[ci++];
         const size_t in_img = (size_t)(h >> ups) * (w >> ups) * in_units * 16;
         const size_t act_img = (size_t)h * w * out_units * 16;
@@ -553,6 +565,8 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             a.out_f32 = out_f32 ? out_f32 + n0 * f32_img : nullptr;
             a.out_nchw = out_nc ? out_nc + n0 * f32_img : nullptr;
             a.out_u8 = out_img ? out_img + n0 * f32_img : nullptr;   // same element count, one byte each
+            a.res_act = res_act ? res_act + n0 * in_img : nullptr;   // a buffer of the input's geometry
+            a.res_act_units = in_units;
             a.res1 = res1 ? res1 + n0 * f32_img : nullptr;
             a.res2 = res2 ? res2 + n0 * f32_img : nullptr;
             a.res1_scale = s1;
@@ -592,6 +606,18 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                     return rc;
             }
             // conv5 + dense skip (:23-24); the third block also folds the RRDB skip (:39).
+            if (rrdb_only) {
+                // the dense skip reads the bf16 activations (units [0, nf) of this block's buffer); only the RRDB skip
+                // keeps an fp32 carrier
+                if (r < 2)
+                    rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, nullptr, 0.2f, nullptr,
+                              0.f, nullptr, nullptr, nullptr, cur);
+                else
+                    rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, nullptr, 0.2f, rrdb_in,
+                              0.2f, R, nullptr, nullptr, cur);
+                if (rc) return rc;
+                continue;
+            }
             const float *res1 = (r == 0) ? rrdb_in : T;
             if (r < 2)
                 rc = conv(cur, ws.blk_units, ws.blk_units, H, W, 0, nxt, ws.blk_units, 0, 1.f, res1, 0.2f, nullptr,
@@ -748,8 +774,9 @@ static bool train_ok(const sr355_generator_cfg *cfg) {
         set_error("training path: bf16 kernels with num_features, growth_channels <= 64 only");
         return false;
     }
-    if (cfg->hr_split == SR355_HR_F16) {
-        set_error("training path: the fp16 HR side (hr_split = 2) is an inference mode; train with hr_split 0 or 1");
+    if (cfg->hr_split == SR355_HR_F16 || cfg->trunk_fp32 == SR355_TRUNK_RRDB) {
+        set_error("training path: the fp16 HR side (hr_split = 2) and RRDB-only fp32 carriers (trunk_fp32 = 2) are "
+                  "inference modes");
         return false;
     }
     return true;

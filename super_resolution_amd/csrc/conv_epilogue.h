@@ -37,6 +37,14 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
         for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : v[j] * a.mask_slope;
     }
     const size_t fidx = (row * a.f32_units + (c0 >> 2)) * W + x;   // in float4 units
+    if constexpr (sizeof(T) == 2) {
+        if (a.res_act) {   // the skip read from the bf16 activations themselves (no fp32 carrier for this skip)
+            const size_t o = ((row * a.res_act_units + (c0 >> 3)) * W + x) * 16 + h * 8;
+            const epi_bf16x4 rv = *reinterpret_cast<const epi_bf16x4 *>(a.res_act + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a.res1_w * (float)rv[j] + a.res1_scale * v[j];
+        }
+    }
     if (a.res1) {
         const float4 rv = reinterpret_cast<const float4 *>(a.res1)[fidx];
         v[0] = a.res1_w * rv.x + a.res1_scale * v[0];

@@ -20,6 +20,9 @@ struct ConvArgs {
     int f16_in;                  // bf16 path only: input and weights hold IEEE fp16 (same 16-byte units, f16 MFMA)
     int f16_out;                 // bf16 path only: out_act is stored as fp16 (it feeds an f16_in conv)
     unsigned char *out_u8;       // uint8 image [N][H][W][cout_real] = trunc(255 * clamp(v, 0, 1)), may be null
+    const unsigned char *res_act; // blocked bf16 activations [N][H][res_act_units][W][16 B] whose channels [0, cout) are
+                                 // the first residual instead of res1 (same weights res1_w / res1_scale), may be null
+    int res_act_units;
     const float *res1;           // fp32 trunk, may be null
     const float *res2;           // fp32 trunk, may be null
     float res1_scale, res2_scale; // v = resK_w * resK + resK_scale * v

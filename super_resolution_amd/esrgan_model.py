@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import ops
-from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16
+from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB
 
 _PRECISIONS = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32, "f32": DTYPE_F32}
 _SLOPE = 0.2
@@ -142,6 +142,10 @@ class GeneratorRRDB(nn.Module):
     the reference itself runs fp16 under autocast, but pass ``False`` for weights with extreme HR-side activations.
     Forwards recorded for backward always use the ``hr_split`` form (the backward kernels read bf16 activations),
     so a grad-mode output and a no-grad output of the same input differ by that rounding (about 1e-3).
+    ``dense_skip_fp32`` (bf16 only): ``False`` (default) lets no-grad forwards add the dense-block skips onto the bf16
+    activations themselves and keep fp32 carriers only for the RRDB and global skips — 41 % fewer epilogue bytes per
+    RRDB, about 3 dB of PSNR (55.6 dB with ``hr_f16``).  ``True`` keeps an fp32 carrier for every skip (58.6 dB);
+    recorded forwards always do.
     ``direct_grads``: the backward pass writes (or adds) every parameter's ``.grad`` itself, as slices of one
     flat buffer, instead of handing 702 gradients to autograd's per-parameter accumulation: the same ``.grad``
     fields after ``loss.backward()`` (optimizers, ``GradScaler``, gradient accumulation see no difference) at a
@@ -150,10 +154,12 @@ class GeneratorRRDB(nn.Module):
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, num_features: int = 64,
                  num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16",
-                 hr_split: bool = True, direct_grads: bool = True, hr_f16: bool = True):
+                 hr_split: bool = True, direct_grads: bool = True, hr_f16: bool = True,
+                 dense_skip_fp32: bool = False):
         super().__init__()
         self.hr_split = bool(hr_split)
         self.hr_f16 = bool(hr_f16)
+        self.dense_skip_fp32 = bool(dense_skip_fp32)
         self.direct_grads = bool(direct_grads)
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
@@ -184,11 +190,12 @@ class GeneratorRRDB(nn.Module):
     def cfg(self, inference: bool = False) -> List[int]:
         """The C-side configuration; ``inference`` selects the fp16 HR side where the module allows it."""
         dtype = _PRECISIONS[self.precision]
-        hr = 0
+        hr, trunk = 0, 1
         if dtype == DTYPE_BF16:
             hr = HR_F16 if (inference and self.hr_f16) else int(self.hr_split)
+            trunk = TRUNK_RRDB if (inference and not self.dense_skip_fp32) else 1
         return [self.in_channels, self.out_channels, self.num_features, self.num_blocks,
-                self.growth_channels, dtype, hr]
+                self.growth_channels, dtype, hr, trunk]
 
     def packed_parameters(self, inference: bool = False) -> Tensor:
         convs = self.conv_modules()

@@ -118,7 +118,7 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
               out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
               mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
               res1_weight: float = 1.0, res2_weight: float = 1.0, f16_in: bool = False,
-              f16_out: bool = False) -> ConvArgs:
+              f16_out: bool = False, res_act: Optional[Tensor] = None) -> ConvArgs:
     """The sr355_conv_args record for one conv launch (the tensors must outlive its use)."""
     _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw, mask)
     a = ConvArgs()
@@ -154,6 +154,9 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
     a.out_f32_dev = _ptr(out_f32)
     a.out_nchw_dev, a.out_nchw_bytes = _ptr(out_nchw), _nbytes(out_nchw)
     a.f16_in, a.f16_out = int(bool(f16_in)), int(bool(f16_out))
+    if res_act is not None:
+        _need_cuda(res_act)
+        a.res_act_dev, a.res_act_bytes, a.res_act_units = res_act.data_ptr(), _nbytes(res_act), int(res_act.shape[2])
     return a
 
 
@@ -255,11 +258,12 @@ def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
 
 # ------------------------------------------------------------------------------------
 def make_cfg(cfg: List[int]) -> GeneratorCfg:
-    """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype, hr_split]."""
+    """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype, hr_split] and optionally
+    trunk_fp32 (default 1: fp32 carriers for every skip)."""
     c = GeneratorCfg()
     (c.in_channels, c.out_channels, c.num_features, c.num_blocks, c.growth_channels, c.dtype,
-     c.hr_split) = [int(v) for v in cfg]
-    c.trunk_fp32 = 1
+     c.hr_split) = [int(v) for v in cfg[:7]]
+    c.trunk_fp32 = int(cfg[7]) if len(cfg) > 7 else 1
     return c
 
 

@@ -313,11 +313,11 @@ def test_generator_call_site_contract():
     # recorded forwards keep the HR side in bf16 (+ weight residue), no-grad ones run it in fp16: same function,
     # different rounding
     assert e.requires_grad and (e.detach() - d).abs().max().item() < 5e-3
-    same = load_net(S.GeneratorRRDB(num_blocks=1, hr_f16=False), sd)
+    same = load_net(S.GeneratorRRDB(num_blocks=1, hr_f16=False, dense_skip_fp32=True), sd)
     with torch.no_grad():
         same.conv_last.bias += 0.25
         assert torch.equal(same(x), same(x.clone().requires_grad_(False)))
-    assert torch.equal(same(x).detach(), torch.no_grad()(same)(x))     # hr_f16=False: one arithmetic in both modes
+    assert torch.equal(same(x).detach(), torch.no_grad()(same)(x))     # one arithmetic in both modes
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -391,16 +391,20 @@ def test_hr_side_modes_clear_the_gate_with_margin():
     with torch.no_grad():
         ref = O.generator_forward(sd, x)
         res, emu = {}, {}
-        for name, kw, mode in (("plain", dict(hr_split=False, hr_f16=False), True),
-                               ("hr_split", dict(hr_split=True, hr_f16=False), "hr_split"),
-                               ("hr_f16", dict(hr_split=True, hr_f16=True), "hr_f16")):
+        for name, kw, mode in (("plain", dict(hr_split=False, hr_f16=False, dense_skip_fp32=True), True),
+                               ("hr_split", dict(hr_split=True, hr_f16=False, dense_skip_fp32=True), "hr_split"),
+                               ("hr_f16", dict(hr_split=True, hr_f16=True, dense_skip_fp32=True), "hr_f16")):
             net = load_net(S.GeneratorRRDB(**kw), sd)
             res[name] = O.psnr(net(x.to(DEV)).cpu(), ref)
             emu[name] = O.psnr(O.generator_forward(sd, x, mode), ref)
-    print("unclamped PSNR vs fp32: " + ", ".join(f"{k} {res[k]:.2f} dB (emulated {emu[k]:.2f})" for k in res))
+        # the default of no-grad forwards: fp16 HR side, dense-block skips on the bf16 activations
+        res["default"] = O.psnr(load_net(S.GeneratorRRDB(), sd)(x.to(DEV)).cpu(), ref)
+    print("unclamped PSNR vs fp32: " + ", ".join(f"{k} {res[k]:.2f} dB" + (f" (emulated {emu[k]:.2f})" if k in emu else "")
+                                                 for k in res))
     assert res["hr_split"] >= 52.0 and res["hr_split"] > res["plain"] + 2.0
     assert res["hr_f16"] >= 56.0 and res["hr_f16"] > res["hr_split"] + 2.0
-    assert all(abs(res[k] - emu[k]) < 1.0 for k in res)
+    assert all(abs(res[k] - emu[k]) < 1.0 for k in emu)
+    assert 53.0 <= res["default"] < res["hr_f16"]
 
 
 def test_config4_large_odd_image_full_and_banded():
