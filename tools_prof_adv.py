@@ -17,8 +17,8 @@ def main():
     netG = S.GeneratorRRDB().to(dev).train()
     netD = S.Discriminator().to(dev).train()
     vgg = S.VGGFeatureExtractor(pretrained=False).to(dev)
-    optG = torch.optim.Adam(netG.parameters(), lr=1e-4)
-    optD = torch.optim.Adam(netD.parameters(), lr=1e-4)
+    optG = S.FlatAdam(netG.parameters(), lr=1e-4)
+    optD = S.FlatAdam(netD.parameters(), lr=1e-4)
     lr = torch.rand(16, 3, 32, 32, device=dev)
     hr = torch.rand(16, 3, 128, 128, device=dev)
     for _ in range(2):
