@@ -64,11 +64,10 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
         if constexpr (sizeof(T) == 2) {
             const size_t o = ((row * a.out_units + a.out_unit_off + (c0 >> 3)) * W + x) * 16 + h * 8;
             if (a.f16_out) {
+                // fp16 ends at 65504: saturate instead of storing an infinity the next conv would turn into NaN
                 epi_f16x4 pk;
-                pk[0] = (_Float16)v[0];
-                pk[1] = (_Float16)v[1];
-                pk[2] = (_Float16)v[2];
-                pk[3] = (_Float16)v[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
                 *reinterpret_cast<epi_f16x4 *>(a.out_act + o) = pk;
             } else {
                 epi_bf16x4 pk;

@@ -427,3 +427,17 @@ def test_config4_large_odd_image_full_and_banded():
           f"4 bands + halo 16 vs whole image {seam:.2f} dB")
     assert clamped >= 50.0 and unclamped >= 50.0
     assert seam >= 50.0          # the halo approximation stays below the bf16 rounding level
+
+
+def test_fp16_hr_side_saturates_instead_of_overflowing():
+    """HR-side activations beyond fp16's range (65504) are stored saturated: the output stays finite, where an
+    unclamped conversion would hand the next conv an infinity."""
+    sd = O.make_generator_state(61, num_blocks=1)
+    sd["upconv1.bias"] = sd["upconv1.bias"] + 1.0e5          # pushes upconv1's output past 65504
+    net = load_net(S.GeneratorRRDB(num_blocks=1), sd)
+    x = torch.rand(1, 3, 8, 8, generator=torch.Generator().manual_seed(62)).to(DEV)
+    with torch.no_grad():
+        out = net(x)
+        wide = load_net(S.GeneratorRRDB(num_blocks=1, hr_f16=False), sd)(x)     # bf16 has the range
+    assert torch.isfinite(out).all() and torch.isfinite(wide).all()
+    assert out.abs().max().item() < wide.abs().max().item()                    # saturated, not equal
