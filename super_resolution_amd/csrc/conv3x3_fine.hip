@@ -310,23 +310,28 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int ty_i = tr % a.tiles_y;
             const int n = tr / a.tiles_y;
             const int x = tx_i * 32 + r;
+            if (conv_epilogue_tile_ok(a)) {
+                conv_epilogue_tile<MB, NB>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x, cb * G::CO, h,
+                                           !(a.debug & 2));
+            } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int y = ty_i * G::TH + wave * NB + nb;
-                const bool ok = (x < W) && (y < H) && !(a.debug & 2);
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int y = ty_i * G::TH + wave * NB + nb;
+                    const bool ok = (x < W) && (y < H) && !(a.debug & 2);
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
+                    for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int cl = mb * 32 + q * 8 + h * 4;
-                        const int c0 = cb * G::CO + cl;
-                        const float4 bv = *reinterpret_cast<const float4 *>(smem + G::BIAS_OFF + cl * 4);
-                        float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
-                                      acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
+                        for (int q = 0; q < 4; ++q) {
+                            const int cl = mb * 32 + q * 8 + h * 4;
+                            const int c0 = cb * G::CO + cl;
+                            const float4 bv = *reinterpret_cast<const float4 *>(smem + G::BIAS_OFF + cl * 4);
+                            float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
+                                          acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
-                        if (!ok || c0 >= a.cout_real) continue;
-                        conv_epilogue_quad<__bf16>(a, v, n, y, x, c0, h);
+                            for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
+                            if (!ok || c0 >= a.cout_real) continue;
+                            conv_epilogue_quad<__bf16>(a, v, n, y, x, c0, h);
+                        }
                     }
                 }
             }

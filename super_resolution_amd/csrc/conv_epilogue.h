@@ -12,6 +12,13 @@ namespace sr355 {
 
 typedef __attribute__((ext_vector_type(4))) __bf16 epi_bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 epi_f16x4;
+typedef __attribute__((ext_vector_type(16))) float epi_f32x16;
+typedef unsigned int epi_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int epi_v4u __attribute__((ext_vector_type(4)));
+typedef float epi_v4f __attribute__((ext_vector_type(4)));
+
+// w * r + s * v, written once so that every epilogue path rounds it the same way
+__device__ __forceinline__ float epi_axpby(float w, float r, float s, float v) { return __builtin_fmaf(w, r, s * v); }
 
 template <typename T>
 __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)[4], int n, int y, int x, int c0,
@@ -42,22 +49,22 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
             const size_t o = ((row * a.res_act_units + (c0 >> 3)) * W + x) * 16 + h * 8;
             const epi_bf16x4 rv = *reinterpret_cast<const epi_bf16x4 *>(a.res_act + o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = a.res1_w * (float)rv[j] + a.res1_scale * v[j];
+            for (int j = 0; j < 4; ++j) v[j] = epi_axpby(a.res1_w, (float)rv[j], a.res1_scale, v[j]);
         }
     }
     if (a.res1) {
         const float4 rv = reinterpret_cast<const float4 *>(a.res1)[fidx];
-        v[0] = a.res1_w * rv.x + a.res1_scale * v[0];
-        v[1] = a.res1_w * rv.y + a.res1_scale * v[1];
-        v[2] = a.res1_w * rv.z + a.res1_scale * v[2];
-        v[3] = a.res1_w * rv.w + a.res1_scale * v[3];
+        v[0] = epi_axpby(a.res1_w, rv.x, a.res1_scale, v[0]);
+        v[1] = epi_axpby(a.res1_w, rv.y, a.res1_scale, v[1]);
+        v[2] = epi_axpby(a.res1_w, rv.z, a.res1_scale, v[2]);
+        v[3] = epi_axpby(a.res1_w, rv.w, a.res1_scale, v[3]);
     }
     if (a.res2) {
         const float4 rv = reinterpret_cast<const float4 *>(a.res2)[fidx];
-        v[0] = a.res2_w * rv.x + a.res2_scale * v[0];
-        v[1] = a.res2_w * rv.y + a.res2_scale * v[1];
-        v[2] = a.res2_w * rv.z + a.res2_scale * v[2];
-        v[3] = a.res2_w * rv.w + a.res2_scale * v[3];
+        v[0] = epi_axpby(a.res2_w, rv.x, a.res2_scale, v[0]);
+        v[1] = epi_axpby(a.res2_w, rv.y, a.res2_scale, v[1]);
+        v[2] = epi_axpby(a.res2_w, rv.z, a.res2_scale, v[2]);
+        v[3] = epi_axpby(a.res2_w, rv.w, a.res2_scale, v[3]);
     }
     if (a.out_f32) reinterpret_cast<float4 *>(a.out_f32)[fidx] = make_float4(v[0], v[1], v[2], v[3]);
     if (a.out_act) {
@@ -96,6 +103,114 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
                 const float cl = v[j] < 0.f ? 0.f : (v[j] > 1.f ? 1.f : v[j]);
                 a.out_u8[((row * W) + x) * a.cout_real + c0 + j] = (unsigned char)(int)(cl * 255.0f);
             }
+    }
+}
+
+// ---- whole-tile epilogue of the ring kernels (bf16 path) ------------------------------------------------------
+// The per-quad form above recomputes 64-bit addresses for every quad and keeps each residual load next to the store
+// that depends on it, so a wave walks through its 16 quads one memory round trip at a time.  For the common shape
+// (no mask, no NCHW / uint8 output, whole 32-channel blocks) this form addresses through buffer descriptors of the
+// tile's image — one 32-bit lane offset per output row, the unit step in the scalar offset — issues the residual
+// loads of four quads together, and drops lanes outside the image by an out-of-range offset instead of a branch.
+// Same arithmetic, in the same order, as conv_epilogue_quad.
+__device__ __forceinline__ bool conv_epilogue_tile_ok(const ConvArgs &a) {
+    return !a.mask_act && !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0;
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16 (&acc)[MB][NB],
+                                                   const unsigned char *bias_lds, int n, int y0, int x, int cb_co,
+                                                   int h, bool live) {
+    constexpr int OOB = 0x7fffff00;
+    const int H = a.H, W = a.W;
+    const int wstep = __builtin_amdgcn_readfirstlane(W * 16);          // bytes from one unit of a row to the next
+    auto rsrc = [&](const void *base, size_t img_bytes) {
+        const unsigned long long p = (unsigned long long)base + (size_t)n * img_bytes;
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p)),
+            0, __builtin_amdgcn_readfirstlane((int)img_bytes), 0x00020000);
+    };
+    const size_t f32_img = (size_t)H * W * a.f32_units * 16;
+    const __amdgpu_buffer_rsrc_t rs_act = rsrc(a.out_act, (size_t)H * W * a.out_units * 16);
+    const __amdgpu_buffer_rsrc_t rs_ra = rsrc(a.res_act, (size_t)H * W * a.res_act_units * 16);
+    const __amdgpu_buffer_rsrc_t rs_r1 = rsrc(a.res1, f32_img);
+    const __amdgpu_buffer_rsrc_t rs_r2 = rsrc(a.res2, f32_img);
+    const __amdgpu_buffer_rsrc_t rs_f32 = rsrc(a.out_f32, f32_img);
+    const float slope = a.slope;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int y = y0 + nb;
+        const bool ok = live && x < W && y < H;
+        const int vo_act = ok ? ((y * a.out_units + a.out_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+        const int vo_ra = ok ? ((y * a.res_act_units + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+        const int vo_f = ok ? ((y * a.f32_units + (cb_co >> 2) + h) * W + x) * 16 : OOB;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            epi_v2u ra[4];
+            epi_v4u r1[4], r2[4];
+            if (a.res_act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ra[q] = __builtin_amdgcn_raw_buffer_load_b64(rs_ra, vo_ra, (mb * 4 + q) * wstep, 0);
+            }
+            if (a.res1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r1[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, vo_f, (mb * 8 + q * 2) * wstep, 0);
+            }
+            if (a.res2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r2[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, vo_f, (mb * 8 + q * 2) * wstep, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = mb * 32 + q * 8 + h * 4;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + cl * 4);
+                float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
+                              acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+                if (a.res_act) {
+                    const epi_bf16x4 rv = __builtin_bit_cast(epi_bf16x4, ra[q]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = epi_axpby(a.res1_w, (float)rv[j], a.res1_scale, v[j]);
+                }
+                if (a.res1) {   // (the whole vector is re-typed: a bit_cast of one indexed element reads element 0)
+                    const epi_v4f rf = __builtin_bit_cast(epi_v4f, r1[q]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = epi_axpby(a.res1_w, rf[j], a.res1_scale, v[j]);
+                }
+                if (a.res2) {
+                    const epi_v4f rf = __builtin_bit_cast(epi_v4f, r2[q]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = epi_axpby(a.res2_w, rf[j], a.res2_scale, v[j]);
+                }
+                if (a.out_f32) {
+                    const epi_v4f of = {v[0], v[1], v[2], v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_f32, vo_f,
+                                                           (mb * 8 + q * 2) * wstep, 0);
+                }
+                if (a.out_act) {
+                    epi_v2u o;
+                    if (a.f16_out) {
+                        epi_f16x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
+                        o = __builtin_bit_cast(epi_v2u, pk);
+                    } else {
+                        epi_bf16x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[j];
+                        o = __builtin_bit_cast(epi_v2u, pk);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_act, vo_act, (mb * 4 + q) * wstep, 0);
+                }
+            }
+        }
     }
 }
 

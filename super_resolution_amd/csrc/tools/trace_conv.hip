@@ -129,6 +129,7 @@ int main(int argc, char **argv) {
     a.in = in, a.w = w, a.bias = bias;
     a.out_act = out;
     a.res1_w = a.res2_w = 1.f, a.res1_scale = a.res2_scale = 0.2f;
+    if (nres < 0) a.res_act = in, a.res_act_units = units;      // the skip read from the bf16 activations
     if (nres >= 1) a.res1 = t1, a.out_f32 = t1;
     if (nres >= 2) a.res2 = t2, a.out_f32 = t2;
     a.mask_slope = 1.f, a.slope = cout == 64 ? 1.f : 0.2f;
