@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
         if (++it_tile < n_my) SR355_TILE_SETUP(it_tile);                                              \
     }
 
+    SR355_FSTAMP(12);
     if (n_my > 0) SR355_TILE_SETUP(0);
+    SR355_FSTAMP(13);
 #pragma unroll
     for (int g = 0; g < R - 1; ++g) {
         SR355_ISSUE_DMA(g);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 
         if (++ct_stage == S) {
             // ---- epilogue of tile ct_tile ----
-            if (ct_tile < 6) SR355_FSTAMP(3 + 2 * ct_tile);
+            if (ct_tile < 4) SR355_FSTAMP(3 + 2 * ct_tile);
             const int t = first + ct_tile * nwg;
             const int tx_i = t % a.tiles_x;
             const int tr = t / a.tiles_x;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
                 }
             }
             ct_stage = 0;
-            if (ct_tile < 6) SR355_FSTAMP(4 + 2 * ct_tile);
+            if (ct_tile < 4) SR355_FSTAMP(4 + 2 * ct_tile);
             ++ct_tile;
         }
     }

@@ -185,7 +185,7 @@ int main(int argc, char **argv) {
     }
     const char *names[16] = {"start", "prologue issued", "stage 0 landed", "tile0 mma done", "tile0 epilogue done",
                              "tile1 mma done", "tile1 epilogue done", "tile2 mma done", "tile2 epi done", "t3 mma",
-                             "t3 epi", "t4 mma", "t4 epi", "t5 mma", "t5 epi", "end"};
+                             "t3 epi", "t4 mma", "args read, before tile set-up", "tile set-up done", "(clock)", "end"};
     for (int k = 0; k < 16; ++k) {
         std::vector<double> v;
         for (int b = 0; b < nwg; ++b)
