@@ -217,6 +217,16 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
                   img_bytes);
         return SR355_ERR_UNSUPPORTED;
     }
+    {   // the epilogue addresses one image of every output / residual tensor with a 31-bit offset as well
+        const size_t px = (size_t)p->H * p->W;
+        const size_t out_img = px * (size_t)(p->out_act_dev ? p->out_units : 0) * 16;
+        const size_t f32_img = px * (size_t)p->cout * 4;
+        const size_t ra_img = px * (size_t)(p->res_act_dev ? p->res_act_units : 0) * 16;
+        if (out_img >= ((size_t)1 << 31) || f32_img >= ((size_t)1 << 31) || ra_img >= ((size_t)1 << 31)) {
+            set_error("conv3x3_fwd: one output / residual image exceeds 2 GiB; the kernel indexes an image with 31 bits");
+            return SR355_ERR_UNSUPPORTED;
+        }
+    }
     if (!p->in_dev || !aligned16(p->in_dev) || p->in_bytes < img_bytes * p->N) {
         set_error("conv3x3_fwd: input buffer missing, misaligned or too small (%zu < %zu)", p->in_bytes,
                   img_bytes * p->N);
