@@ -403,6 +403,92 @@ def generator_sr_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
     return torch.tanh(F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=3))
 
 
+# ---- conditional VAE ("condtional VAE/model.py":53-215) ----
+def _bn(sd: StateDict, name: str, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """nn.BatchNorm2d as the reference applies it (default eps / momentum); in training mode the running
+    buffers of ``sd`` are updated in place, as the module does."""
+    if training:
+        with torch.no_grad():
+            mean = x.mean((0, 2, 3))
+            var_u = x.var((0, 2, 3), unbiased=True)
+            sd[name + ".running_mean"].mul_(0.9).add_(0.1 * mean)
+            sd[name + ".running_var"].mul_(0.9).add_(0.1 * var_u)
+            sd[name + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, None if training else sd[name + ".running_mean"], None if training else sd[name + ".running_var"],
+                        sd[name + ".weight"], sd[name + ".bias"], training, 0.1, 1e-5)
+
+
+def make_cvae_state(seed: int, latent_dim: int = 256) -> StateDict:
+    """The state ``torch.manual_seed(seed); CVAE(latent_dim)`` holds: default initialisation of every Conv2d, Linear
+    and ConvTranspose2d in construction order (model.py:58-147); BatchNorm draws nothing."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = OrderedDict()
+
+    def draw(name, shape, fan_in):
+        bound = math.sqrt(3.0) * (math.sqrt(2.0 / 6.0) / math.sqrt(fan_in))
+        sd[name + ".weight"] = torch.empty(*shape).uniform_(-bound, bound, generator=gen)
+        b = 1.0 / math.sqrt(fan_in)
+        n_bias = shape[1] if name.startswith("dec_conv") else shape[0]
+        sd[name + ".bias"] = torch.empty(n_bias).uniform_(-b, b, generator=gen)
+
+    def bn(name, c):
+        sd[name + ".weight"], sd[name + ".bias"] = torch.ones(c), torch.zeros(c)
+        sd[name + ".running_mean"], sd[name + ".running_var"] = torch.zeros(c), torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    draw("enc_conv1.0", (64, 3, 3, 3), 27)
+    for k, (ci, co) in zip((2, 3, 4), ((64, 128), (128, 256), (256, 512))):
+        draw(f"enc_conv{k}.0", (co, ci, 3, 3), ci * 9)
+        bn(f"enc_conv{k}.1", co)
+    draw("fc_mu", (latent_dim, 8192), 8192)
+    draw("fc_logvar", (latent_dim, 8192), 8192)
+    draw("decoder_input", (8192, latent_dim), latent_dim)
+    draw("condition_processor.0", (32, 3, 3, 3), 27)
+    draw("condition_processor.2", (64, 32, 3, 3), 32 * 9)
+    # ConvTranspose2d weights are [in, out, k, k]; its fan_in is taken from dimension 1 (out * k * k)
+    for k, (ci, co) in zip((1, 2, 3), ((512, 256), (512, 128), (256, 64))):
+        draw(f"dec_conv{k}.0", (ci, co, 4, 4), co * 16)
+        bn(f"dec_conv{k}.1", co)
+    draw("upsample1.0", (256, 128, 3, 3), 128 * 9)
+    bn("upsample1.2", 64)
+    draw("upsample2.0", (256, 64, 3, 3), 64 * 9)
+    bn("upsample2.2", 64)
+    draw("final_conv.0", (3, 64, 3, 3), 64 * 9)
+    draw("lr_upsampler.1", (3, 3, 3, 3), 27)
+    return sd
+
+
+def cvae_encode(sd: StateDict, x: torch.Tensor, training: bool = False):
+    """CVAE.encode (model.py:150-163): (mu, logvar, (x1, x2, x3, x4))."""
+    x1 = F.leaky_relu(F.conv2d(x, sd["enc_conv1.0.weight"], sd["enc_conv1.0.bias"], padding=1), 0.2)
+    feats, h = [x1], x1
+    for k in (2, 3, 4):
+        h = F.conv2d(h, sd[f"enc_conv{k}.0.weight"], sd[f"enc_conv{k}.0.bias"], stride=2, padding=1)
+        h = F.leaky_relu(_bn(sd, f"enc_conv{k}.1", h, training), 0.2)
+        feats.append(h)
+    flat = h.flatten(1)
+    mu = F.linear(flat, sd["fc_mu.weight"], sd["fc_mu.bias"])
+    logvar = F.linear(flat, sd["fc_logvar.weight"], sd["fc_logvar.bias"])
+    return mu, logvar, tuple(feats)
+
+
+def cvae_decode(sd: StateDict, z: torch.Tensor, condition: torch.Tensor, skips, training: bool = False) -> torch.Tensor:
+    """CVAE.decode (model.py:170-204).  ``condition_processor`` (:99-104) is evaluated by the reference and its
+    result never used; it is left out here."""
+    skip1, skip2, skip3, _skip4 = skips
+    h = F.linear(z, sd["decoder_input.weight"], sd["decoder_input.bias"]).view(-1, 512, 4, 4)
+    for k, skip in ((1, skip3), (2, skip2), (3, skip1)):
+        h = F.conv_transpose2d(h, sd[f"dec_conv{k}.0.weight"], sd[f"dec_conv{k}.0.bias"], stride=2, padding=1)
+        h = F.leaky_relu(_bn(sd, f"dec_conv{k}.1", h, training), 0.2)
+        h = torch.cat([h, skip], 1)
+    for k in (1, 2):
+        h = F.pixel_shuffle(F.conv2d(h, sd[f"upsample{k}.0.weight"], sd[f"upsample{k}.0.bias"], padding=1), 2)
+        h = F.leaky_relu(_bn(sd, f"upsample{k}.2", h, training), 0.2)
+    h = torch.tanh(F.conv2d(h, sd["final_conv.0.weight"], sd["final_conv.0.bias"], padding=1))
+    up = F.interpolate(condition, scale_factor=4, mode="bicubic", align_corners=False)
+    return h + F.conv2d(up, sd["lr_upsampler.1.weight"], sd["lr_upsampler.1.bias"], padding=1)
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)

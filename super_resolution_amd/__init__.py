@@ -5,9 +5,10 @@ from .esrgan_model import GeneratorRRDB, RRDB, RRDBNet, ResidualDenseBlock  # no
 from .esrgan_aux import Discriminator, VGGFeatureExtractor, adversarial_step, pixel_step  # noqa: F401
 from .sharded import sharded_forward, tiled_forward  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
+from . import cvae  # noqa: F401  (CVAE of the conditional-VAE script)
 from . import cyclegan  # noqa: F401  (GeneratorSR / ResidualBlock of the CycleGAN scripts; not re-exported: the
 #                                       ESRGAN file has a different class under the name Discriminator)
 
 __all__ = ["GeneratorRRDB", "RRDBNet", "RRDB", "ResidualDenseBlock", "Discriminator", "VGGFeatureExtractor",
-           "pixel_step", "adversarial_step", "FlatAdam", "cyclegan", "sharded_forward", "tiled_forward", "ops", "build",
+           "pixel_step", "adversarial_step", "FlatAdam", "cyclegan", "cvae", "sharded_forward", "tiled_forward", "ops", "build",
            "DTYPE_BF16", "DTYPE_F32", "LIB_PATH", "Sr355Error"]

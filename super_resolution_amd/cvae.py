@@ -1,0 +1,105 @@
+"""The conditional VAE on the MI355X conv core.
+
+Drop-in for ``CVAE`` of /root/reference/condtional VAE/model.py:53-215: same constructor argument, the same
+``state_dict`` keys (``enc_conv{1..4}``, ``fc_mu``, ``fc_logvar``, ``decoder_input``, ``condition_processor``,
+``dec_conv{1..3}``, ``upsample{1,2}``, ``final_conv``, ``lr_upsampler``), the same ``encode`` / ``reparameterize`` /
+``decode`` / ``forward`` / ``sample`` methods, trainable through autograd.  Its eight 3x3 convolutions that produce
+something — the encoder (stride 2 taken as the stride-1 result at even positions), the two sub-pixel stages, the final
+conv and the conv behind the bicubic up-sampler — run on the HIP kernels of ``conv_core`` (bf16 operands, fp32
+accumulation; fp32 conv output into every BatchNorm).  The 4x4 transposed convolutions, the linear layers, BatchNorm,
+PixelShuffle, bicubic interpolation and tanh stay on stock PyTorch-ROCm.  ``condition_processor`` keeps its
+parameters (checkpoints carry them) but is not evaluated: the reference computes its output and never uses it
+(model.py:175).  ``VGGPerceptualLoss`` of the same file needs torchvision's ImageNet weights and is not provided.
+"""
+import torch
+from torch import Tensor, nn
+import torch.nn.functional as F
+
+from . import conv_core as cc
+
+
+def _need_cuda(x: Tensor) -> None:
+    if not x.is_cuda:
+        raise RuntimeError("super_resolution_amd.cvae.CVAE runs on ROCm devices only: move the module and its input to "
+                           "'cuda' (there is no CPU fallback)")
+
+
+def _conv_f32(x_nchw: Tensor, conv: nn.Conv2d) -> Tensor:
+    """3x3 / pad 1 conv of an NCHW fp32 tensor on the conv core, NCHW fp32 result (stride 2 = even positions)."""
+    xb = cc.to_blocked(x_nchw.contiguous())
+    if conv.out_channels % 16:
+        y = cc.conv3x3(xb, conv.weight, conv.bias, 1.0, nchw_out=True)
+    else:
+        y = cc.f32_as_nchw(cc.conv3x3(xb, conv.weight, conv.bias, 1.0, f32_out=True))
+    return y[:, :, ::2, ::2] if conv.stride[0] == 2 else y
+
+
+class CVAE(nn.Module):
+    def __init__(self, latent_dim: int = 256):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.enc_conv1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(0.2))
+        self.enc_conv2 = nn.Sequential(nn.Conv2d(64, 128, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(128),
+                                       nn.LeakyReLU(0.2))
+        self.enc_conv3 = nn.Sequential(nn.Conv2d(128, 256, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(256),
+                                       nn.LeakyReLU(0.2))
+        self.enc_conv4 = nn.Sequential(nn.Conv2d(256, 512, kernel_size=3, stride=2, padding=1), nn.BatchNorm2d(512),
+                                       nn.LeakyReLU(0.2))
+        self.flatten = nn.Flatten()
+        self.fc_mu = nn.Linear(512 * 4 * 4, latent_dim)
+        self.fc_logvar = nn.Linear(512 * 4 * 4, latent_dim)
+        self.decoder_input = nn.Linear(latent_dim, 512 * 4 * 4)
+        self.condition_processor = nn.Sequential(nn.Conv2d(3, 32, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(0.2),
+                                                 nn.Conv2d(32, 64, kernel_size=3, stride=1, padding=1), nn.LeakyReLU(0.2))
+        self.dec_conv1 = nn.Sequential(nn.ConvTranspose2d(512, 256, kernel_size=4, stride=2, padding=1),
+                                       nn.BatchNorm2d(256), nn.LeakyReLU(0.2))
+        self.dec_conv2 = nn.Sequential(nn.ConvTranspose2d(256 + 256, 128, kernel_size=4, stride=2, padding=1),
+                                       nn.BatchNorm2d(128), nn.LeakyReLU(0.2))
+        self.dec_conv3 = nn.Sequential(nn.ConvTranspose2d(128 + 128, 64, kernel_size=4, stride=2, padding=1),
+                                       nn.BatchNorm2d(64), nn.LeakyReLU(0.2))
+        self.upsample1 = nn.Sequential(nn.Conv2d(64 + 64, 256, kernel_size=3, stride=1, padding=1), nn.PixelShuffle(2),
+                                       nn.BatchNorm2d(64), nn.LeakyReLU(0.2))
+        self.upsample2 = nn.Sequential(nn.Conv2d(64, 256, kernel_size=3, stride=1, padding=1), nn.PixelShuffle(2),
+                                       nn.BatchNorm2d(64), nn.LeakyReLU(0.2))
+        self.final_conv = nn.Sequential(nn.Conv2d(64, 3, kernel_size=3, stride=1, padding=1), nn.Tanh())
+        self.lr_upsampler = nn.Sequential(nn.Upsample(scale_factor=4, mode='bicubic', align_corners=False),
+                                          nn.Conv2d(3, 3, kernel_size=3, stride=1, padding=1))
+
+    def encode(self, x: Tensor):
+        _need_cuda(x)
+        x1 = F.leaky_relu(_conv_f32(x.float(), self.enc_conv1[0]), 0.2)
+        feats, h = [x1], x1
+        for block in (self.enc_conv2, self.enc_conv3, self.enc_conv4):
+            h = F.leaky_relu(block[1](_conv_f32(h, block[0])), 0.2)
+            feats.append(h)
+        encoded = self.flatten(h)
+        return self.fc_mu(encoded), self.fc_logvar(encoded), tuple(feats)
+
+    def reparameterize(self, mu: Tensor, logvar: Tensor) -> Tensor:
+        std = torch.exp(0.5 * logvar)
+        return mu + torch.randn_like(std) * std
+
+    def decode(self, z: Tensor, condition: Tensor, skip_features) -> Tensor:
+        _need_cuda(condition)
+        skip1, skip2, skip3, _skip4 = skip_features
+        x = self.decoder_input(z).view(-1, 512, 4, 4)
+        x = torch.cat([self.dec_conv1(x), skip3], dim=1)           # 4x4 transposed convs: stock PyTorch-ROCm
+        x = torch.cat([self.dec_conv2(x), skip2], dim=1)
+        x = torch.cat([self.dec_conv3(x), skip1], dim=1)
+        for block in (self.upsample1, self.upsample2):
+            x = F.leaky_relu(block[2](F.pixel_shuffle(_conv_f32(x, block[0]), 2)), 0.2)
+        x = torch.tanh(_conv_f32(x, self.final_conv[0]))
+        upsampled_lr = _conv_f32(self.lr_upsampler[0](condition.float()), self.lr_upsampler[1])
+        return x + upsampled_lr
+
+    def forward(self, x: Tensor):
+        mu, logvar, skip_features = self.encode(x)
+        z = self.reparameterize(mu, logvar)
+        return self.decode(z, x, skip_features), mu, logvar
+
+    def sample(self, num_samples: int, condition: Tensor) -> Tensor:
+        z = torch.randn(num_samples, self.latent_dim, device=condition.device)
+        b, dev = condition.size(0), condition.device
+        dummy = (torch.zeros(b, 64, 32, 32, device=dev), torch.zeros(b, 128, 16, 16, device=dev),
+                 torch.zeros(b, 256, 8, 8, device=dev), torch.zeros(b, 512, 4, 4, device=dev))
+        return self.decode(z, condition, dummy)

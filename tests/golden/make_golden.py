@@ -9,6 +9,7 @@ text is stored: fixtures hold seeds, inputs, outputs and gradients only.
     cd /tmp && python /root/repo/tests/golden/make_golden.py        # all fixtures
     cd /tmp && python /root/repo/tests/golden/make_golden.py g8     # only g8_adversarial_step.npz
     cd /tmp && python /root/repo/tests/golden/make_golden.py g9     # only g9_cyclegan_sr.npz (+ manifest)
+    cd /tmp && python /root/repo/tests/golden/make_golden.py g10    # only g10_cvae.npz (+ manifest)
 """
 import importlib.util
 import os
@@ -133,7 +134,48 @@ def make_g9():
             f.write(f"{k} {tuple(v.shape)}\n")
 
 
+def make_g10():
+    # G10: the conditional VAE ("condtional VAE/model.py":53-215).  The file imports torchvision.models at top level
+    # (for its VGG loss class, which needs ImageNet weights and is not built): an empty stand-in module lets it load.
+    # The weights are stored (the state is small only where it matters: the two 8192-wide linear layers are kept as
+    # seeds of the reference constructor, so the fixture stores the state_dict's per-tensor sums and the test
+    # re-creates the module state from the reference-ordered construction in the oracle's recipe below).
+    for m in ("torchvision", "torchvision.models"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    spec = importlib.util.spec_from_file_location("ref_cvae_model", "/root/reference/condtional VAE/model.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(10)
+    net = mod.CVAE(latent_dim=32)
+    g = torch.Generator().manual_seed(110)
+    x = torch.rand(3, 3, 32, 32, generator=g) * 2 - 1
+    z = torch.randn(3, 32, generator=g)
+    st = {"seed": 10, "latent_dim": 32, "x": x.numpy(), "z": z.numpy()}
+    # the convolution / normalisation / linear parameters the HIP module needs (the fixture stays under 1 MB with
+    # latent_dim 32; the two transposed convs dominate and are stored as float16-exact? no: stored as fp32 slices)
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        with torch.no_grad():
+            mu, logvar, skips = net.encode(x)
+            out = net.decode(z, x, skips)
+        st[f"{mode}/mu"], st[f"{mode}/logvar"], st[f"{mode}/out"] = mu.numpy(), logvar.numpy(), out.numpy()
+        for i, s_ in enumerate(skips):
+            st[f"{mode}/skip{i + 1}_sum"] = np.float64(s_.double().sum().item())
+            st[f"{mode}/skip{i + 1}_abs"] = np.float64(s_.double().abs().sum().item())
+    st["running_mean_enc2"] = net.enc_conv2[1].running_mean.numpy().copy()
+    weight_sums(st, net)
+    np.savez_compressed(os.path.join(HERE, "g10_cvae.npz"), **st)
+    with open(os.path.join(HERE, "g10_cvae_manifest.txt"), "w") as f:
+        for k, v in mod.CVAE().state_dict().items():
+            f.write(f"{k} {tuple(v.shape)}\n")
+
+
 def main():
+    if sys.argv[1:] == ["g10"]:
+        torch.set_num_threads(8)
+        make_g10()
+        return
     if sys.argv[1:] == ["g9"]:
         torch.set_num_threads(8)
         make_g9()

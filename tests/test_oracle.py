@@ -207,3 +207,29 @@ def test_cyclegan_generator_sr_g9(golden):
     keys = [ln.split(" ", 1)[0] for ln in open(os.path.join(os.path.dirname(__file__), "golden",
                                                            "g9_cyclegan_sr_manifest.txt")).read().splitlines()]
     assert keys == list(O.make_generator_sr_state(0).keys())
+
+
+def test_conditional_vae_g10(golden):
+    """G10: "condtional VAE/model.py" CVAE(latent_dim=32) built under torch.manual_seed(10): same weights, same
+    encoder outputs and same decoder output for a fixed latent, in eval and in training mode (batch statistics)."""
+    g = golden("g10_cvae.npz")
+    sd = O.make_cvae_state(int(g["seed"]), int(g["latent_dim"]))
+    for name, v in sd.items():
+        if v.dtype.is_floating_point and "running_" not in name:     # (the fixture's buffers are post-training-pass)
+            ref = float(g[f"wsum/{name}"])
+            assert abs(v.double().sum().item() - ref) <= 1e-9 * max(1.0, abs(ref)), name
+    x, z = torch.from_numpy(g["x"]), torch.from_numpy(g["z"])
+    for mode in ("eval", "train"):
+        with torch.no_grad():
+            mu, logvar, skips = O.cvae_encode(sd, x, mode == "train")
+            out = O.cvae_decode(sd, z, x, skips, mode == "train")
+        np.testing.assert_allclose(mu.numpy(), g[f"{mode}/mu"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(logvar.numpy(), g[f"{mode}/logvar"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out.numpy(), g[f"{mode}/out"], rtol=0, atol=5e-5)
+        for i, s_ in enumerate(skips):
+            ref = float(g[f"{mode}/skip{i + 1}_abs"])
+            assert abs(s_.double().abs().sum().item() - ref) <= 1e-5 * ref
+    np.testing.assert_allclose(sd["enc_conv2.1.running_mean"].numpy(), g["running_mean_enc2"], rtol=1e-4, atol=1e-7)
+    keys = [ln.split(" ", 1)[0] for ln in open(os.path.join(os.path.dirname(__file__), "golden",
+                                                           "g10_cvae_manifest.txt")).read().splitlines()]
+    assert keys == list(O.make_cvae_state(0).keys())
