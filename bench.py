@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (no sparsity)
+PEAK_HBM_GBPS = 8000.0          # MI355X HBM3E peak
 FLOP_PER_LR_PIXEL = 35_853_696  # 2 * 17,926,848 MAC for the default generator
 
 
@@ -168,6 +169,13 @@ def roofline_from(rows):
                               "of this command with --streams 1)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),
+            # the same launch against the memory roof: below the ridge (peak FLOP/s / peak B/s) the algorithmic bytes,
+            # not the matrix pipe, set the floor of a launch
+            "hbm_side": {"achieved": round(d["bytes_per_launch"] / (d["avg_launch_us"] * 1e-6) / 1e9, 1),
+                         "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(d["bytes_per_launch"] / (d["avg_launch_us"] * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4),
+                         "flop_per_byte": round(d["flop_per_launch"] / d["bytes_per_launch"], 1),
+                         "ridge_flop_per_byte": round(PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9), 1)},
             "how": "whole-batch launches of every conv shape of one forward, in the forward's launch mix, back to back on "
                    "one stream between two HIP events; the timed forwards themselves run two half-batches on two "
                    "streams, where launches overlap and a per-launch duration is not a kernel rate"}
