@@ -188,6 +188,27 @@ def roofline_from(rows):
     return roof, other, per_shape
 
 
+def host_buffer_rate(net, B, H, W, dev, steps=20):
+    """The image path with the batch starting and ending in pinned host memory: uint8 HWC host -> device, the
+    generator with byte conversion fused at both ends, uint8 HWC device -> host.  A reported extra; the headline
+    value keeps its inputs resident in HBM."""
+    src = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7)).pin_memory()
+    dst = torch.empty((B, 4 * H, 4 * W, 3), dtype=torch.uint8).pin_memory()
+    with torch.no_grad():
+        for _ in range(3):
+            dst.copy_(net.upscale_u8(src.to(dev, non_blocking=True)), non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dst.copy_(net.upscale_u8(src.to(dev, non_blocking=True)), non_blocking=True)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+    return {"value": round(B * 16 * H * W / sec / 1e6, 2), "unit": "HR Mpix/s", "ms_per_step": round(sec * 1e3, 3),
+            "what": f"uint8 [N,H,W,3] batch of {B} from pinned host memory, x4 image back into pinned host memory "
+                    f"({B * H * W * 3 / 1e6:.2f} MB in, {B * 16 * H * W * 3 / 1e6:.2f} MB out per step), one stream, no "
+                    "copy/compute overlap between steps"}
+
+
 def cpu_baseline(H, W):
     """The oracle on the host cores, one patch of the benchmark workload (same generator, fp32)."""
     from oracle import esrgan_oracle as O
@@ -441,6 +462,11 @@ def main():
             line["kernel_shapes"] = per_shape
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(H, W)
+        if world == 1 and not args.no_roofline:
+            try:
+                line["pcie_inclusive"] = host_buffer_rate(net, B, H, W, dev)
+            except Exception as exc:      # an extra: the headline number stands on its own
+                line["pcie_inclusive"] = {"error": f"{type(exc).__name__}: {exc}"}
     hung = False
     if not args.no_train:
         del out
