@@ -126,7 +126,9 @@ class _Conv3x3(torch.autograd.Function):
         else:
             if cout % 4:
                 raise RuntimeError("conv3x3: blocked outputs need a multiple of 4 output channels")
-            y = torch.zeros((N, H, units_for(cout), W, 8), dtype=torch.bfloat16, device=x.device)
+            # the kernel writes every real channel of every pixel: only padding channels need the zero fill
+            alloc = torch.empty if units_for(cout) * 8 == cout else torch.zeros
+            y = alloc((N, H, units_for(cout), W, 8), dtype=torch.bfloat16, device=x.device)
             ops.conv3x3_fwd(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, y, 0, None, None)
         ctx.save_for_backward(x, weight, bias, y if (slope != 1.0 and out_kind == "blocked") else None)
         ctx.slope, ctx.out_kind = float(slope), out_kind
@@ -146,13 +148,16 @@ class _Conv3x3(torch.autograd.Function):
             dyb = dyb.to(torch.bfloat16).contiguous()
         else:
             dyb = dy.contiguous()
-            if y is not None:                       # derivative of the fused LeakyReLU / ReLU
-                dyb = torch.where(y > 0, dyb, dyb * ctx.slope)
+            if y is not None:                       # derivative of the fused LeakyReLU / ReLU, one kernel
+                # (the output has the sign of the pre-activation, so it can stand in for it)
+                dyb = (torch.ops.aten.threshold_backward(dyb, y, 0.0) if ctx.slope == 0.0
+                       else torch.ops.aten.leaky_relu_backward(dyb, y, ctx.slope, False))
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt, zero_bias = _packs_of(weight).backward_pack(weight, bias)
             n_out = (cin + 3) // 4 * 4
-            dx = torch.zeros((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
+            alloc = torch.empty if U * 8 == n_out else torch.zeros
+            dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
             ops.conv3x3_fwd(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight, dtype=torch.float32)
