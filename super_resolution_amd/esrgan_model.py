@@ -14,6 +14,7 @@ There is no CPU path: tensors must live on a ROCm device.
 """
 from __future__ import annotations
 
+import operator
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -24,6 +25,7 @@ from . import ops
 from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB
 
 _PRECISIONS = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32, "f32": DTYPE_F32}
+_VERSION_OF = operator.attrgetter("_version")
 _SLOPE = 0.2
 _RES = 0.2
 
@@ -41,7 +43,7 @@ class _PackCache:
         self.value = None
 
     def get(self, params: List[Tensor], dtype: int, builder):
-        key = (dtype, params[0].device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        key = (dtype, params[0].device, tuple(map(_VERSION_OF, params)), tuple(map(Tensor.data_ptr, params)))
         if key != self.key:
             self.value = builder()
             self.key = key
@@ -179,13 +181,26 @@ class GeneratorRRDB(nn.Module):
 
     # -- parameter plumbing ---------------------------------------------------------------
     def conv_modules(self) -> List[nn.Conv2d]:
-        """The convs in state_dict order."""
-        mods = [self.conv_first]
-        for rrdb in self.body:
-            for r in (1, 2, 3):
-                mods.extend(getattr(rrdb, f"rdb{r}")._convs())
-        mods += [self.trunk_conv, self.upconv1, self.upconv2, self.HR_conv, self.conv_last]
+        """The convs in state_dict order (the module tree is fixed at construction: walked once)."""
+        mods = self.__dict__.get("_conv_list")
+        if mods is None:
+            mods = [self.conv_first]
+            for rrdb in self.body:
+                for r in (1, 2, 3):
+                    mods.extend(getattr(rrdb, f"rdb{r}")._convs())
+            mods += [self.trunk_conv, self.upconv1, self.upconv2, self.HR_conv, self.conv_last]
+            self.__dict__["_conv_list"] = mods
         return mods
+
+    def conv_parameters(self) -> List[Tensor]:
+        """weight, bias of every conv in state_dict order, read from the modules on every call (a parameter may
+        have been replaced since the last one)."""
+        out = []
+        for c in self.conv_modules():
+            d = c._parameters
+            out.append(d["weight"])
+            out.append(d["bias"])
+        return out
 
     def cfg(self, inference: bool = False) -> List[int]:
         """The C-side configuration; ``inference`` selects the fp16 HR side where the module allows it."""
@@ -198,12 +213,10 @@ class GeneratorRRDB(nn.Module):
                 self.growth_channels, dtype, hr, trunk]
 
     def packed_parameters(self, inference: bool = False) -> Tensor:
-        convs = self.conv_modules()
-        params = [p for c in convs for p in (c.weight, c.bias)]
+        params = self.conv_parameters()
         cfg = self.cfg(inference)
         cache = self._cache_inf if cfg[6] == HR_F16 else self._cache
-        return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack(
-            [c.weight.detach() for c in convs], [c.bias.detach() for c in convs], cfg))
+        return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack_now(params[0::2], params[1::2], cfg))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:
         need = ops.generator_workspace_bytes(self.cfg(), N, H, W)
@@ -215,16 +228,15 @@ class GeneratorRRDB(nn.Module):
         return ws
 
     def packed_bwd_parameters(self) -> Tensor:
-        convs = self.conv_modules()
+        weights = self.conv_parameters()[0::2]
         cfg = self.cfg()
-        return self._cache_bwd.get([c.weight for c in convs], (cfg[5], cfg[6]),
-                                   lambda: ops.generator_pack_bwd([c.weight.detach() for c in convs], cfg))
+        return self._cache_bwd.get(weights, (cfg[5], cfg[6]), lambda: ops.generator_pack_bwd_now(weights, cfg))
 
     # -- forward --------------------------------------------------------------------------
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
         xin = x.float().contiguous()
-        params = [p for c in self.conv_modules() for p in (c.weight, c.bias)]
+        params = self.conv_parameters()
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
             if _PRECISIONS[self.precision] != DTYPE_BF16:
                 raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
@@ -301,7 +313,7 @@ class _GeneratorFunction(torch.autograd.Function):
             reduce_in_buckets(flat, ctx.reducer.buckets,
                               lambda pb, pe: ops.generator_backward_range(gout, packed_bwd, ctx.saved, ws, flat, gin, cfg,
                                                                           H, W, pb, pe), ctx.reducer.group)
-        params = [p for c in module.conv_modules() for p in (c.weight, c.bias)]
+        params = module.conv_parameters()
         # one split for all 702 slices, then a reshape of the 4-d ones (biases are 1-d already)
         views = list(flat.split_with_sizes([p.numel() for p in params]))
         for i in range(0, len(views), 2):

@@ -283,9 +283,10 @@ def generator_workspace_bytes(cfg: List[int], N: int, H: int, W: int) -> int:
     return n
 
 
-@torch.library.custom_op("sr355::generator_pack", mutates_args=())
-def generator_pack(weights: List[Tensor], biases: List[Tensor], cfg: List[int]) -> Tensor:
-    """Pack all conv parameters (state_dict order) into one device blob."""
+def generator_pack_now(weights: List[Tensor], biases: List[Tensor], cfg: List[int]) -> Tensor:
+    """What ``sr355::generator_pack`` runs, callable without the dispatcher: the op reads the parameters' memory
+    and nothing else of them, so a module that repacks 702 tensors every training step calls this with its
+    Parameters as they are (no detached aliases, no per-tensor dispatch bookkeeping)."""
     _need_cuda(*weights, *biases)
     c = make_cfg(cfg)
     L = _lib.lib()
@@ -301,6 +302,12 @@ def generator_pack(weights: List[Tensor], biases: List[Tensor], cfg: List[int]) 
         check(L.sr355_generator_pack(C.byref(c), wp, bp, n, blob.data_ptr(), nbytes, _stream()),
               "sr355_generator_pack")
     return blob
+
+
+@torch.library.custom_op("sr355::generator_pack", mutates_args=())
+def generator_pack(weights: List[Tensor], biases: List[Tensor], cfg: List[int]) -> Tensor:
+    """Pack all conv parameters (state_dict order) into one device blob."""
+    return generator_pack_now(weights, biases, cfg)
 
 
 @generator_pack.register_fake
@@ -404,9 +411,8 @@ def _(x, packed, saved, workspace, cfg):
     return x.new_empty((N, cfg[1], 4 * H, 4 * W), dtype=torch.float32)
 
 
-@torch.library.custom_op("sr355::generator_pack_bwd", mutates_args=())
-def generator_pack_bwd(weights: List[Tensor], cfg: List[int]) -> Tensor:
-    """Transposed (data-gradient) packing of every conv weight (state_dict order)."""
+def generator_pack_bwd_now(weights: List[Tensor], cfg: List[int]) -> Tensor:
+    """What ``sr355::generator_pack_bwd`` runs, callable without the dispatcher (see ``generator_pack_now``)."""
     _need_cuda(*weights)
     c = make_cfg(cfg)
     L = _lib.lib()
@@ -420,6 +426,12 @@ def generator_pack_bwd(weights: List[Tensor], cfg: List[int]) -> Tensor:
         check(L.sr355_generator_pack_bwd(C.byref(c), wp, n, blob.data_ptr(), nbytes, _stream()),
               "sr355_generator_pack_bwd")
     return blob
+
+
+@torch.library.custom_op("sr355::generator_pack_bwd", mutates_args=())
+def generator_pack_bwd(weights: List[Tensor], cfg: List[int]) -> Tensor:
+    """Transposed (data-gradient) packing of every conv weight (state_dict order)."""
+    return generator_pack_bwd_now(weights, cfg)
 
 
 @generator_pack_bwd.register_fake
