@@ -34,22 +34,22 @@ class _ToBlocked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor) -> Tensor:
         ctx.channels = x.shape[1]
-        return ops.to_blocked(x.detach().float().contiguous(), units_for(x.shape[1]), DTYPE_BF16)
+        return ops.to_blocked_now(x.detach().float().contiguous(), units_for(x.shape[1]), DTYPE_BF16)
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        return ops.from_blocked(g.contiguous(), 0, ctx.channels)
+        return ops.from_blocked_now(g.contiguous(), 0, ctx.channels)
 
 
 class _FromBlocked(torch.autograd.Function):
     @staticmethod
     def forward(ctx, buf: Tensor, channels: int) -> Tensor:
         ctx.units = buf.shape[2]
-        return ops.from_blocked(buf.detach().contiguous(), 0, channels)
+        return ops.from_blocked_now(buf.detach().contiguous(), 0, channels)
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        return ops.to_blocked(g.float().contiguous(), ctx.units, DTYPE_BF16), None
+        return ops.to_blocked_now(g.float().contiguous(), ctx.units, DTYPE_BF16), None
 
 
 def to_blocked(x: Tensor) -> Tensor:
@@ -117,19 +117,19 @@ class _Conv3x3(torch.autograd.Function):
             raise RuntimeError(f"conv3x3: unknown output kind {out_kind!r}")
         if nchw_out:
             y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
-            ops.conv3x3_fwd(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, None, 0, None, y)
+            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, None, 0, None, y)
         elif out_kind == "f32":
             if cout % 16 or slope != 1.0:
                 raise RuntimeError("conv3x3: fp32 outputs need a multiple of 16 channels and no fused activation")
             y = torch.empty((N, H, cout // 4, W, 4), dtype=torch.float32, device=x.device)
-            ops.conv3x3_fwd(x, units_for(cin), wp, bp, cout, 1.0, 0, None, 0.0, None, 0.0, None, 0, y, None)
+            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, 1.0, 0, None, 0.0, None, 0.0, None, 0, y, None)
         else:
             if cout % 4:
                 raise RuntimeError("conv3x3: blocked outputs need a multiple of 4 output channels")
             # the kernel writes every real channel of every pixel: only padding channels need the zero fill
             alloc = torch.empty if units_for(cout) * 8 == cout else torch.zeros
             y = alloc((N, H, units_for(cout), W, 8), dtype=torch.bfloat16, device=x.device)
-            ops.conv3x3_fwd(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, y, 0, None, None)
+            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, y, 0, None, None)
         ctx.save_for_backward(x, weight, bias, y if (slope != 1.0 and out_kind == "blocked") else None)
         ctx.slope, ctx.out_kind = float(slope), out_kind
         return y
@@ -142,7 +142,7 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.out_kind == "nchw":
             if ctx.slope != 1.0:
                 raise RuntimeError("conv3x3: an NCHW output carries no fused activation")
-            dyb = ops.to_blocked(dy.float().contiguous(), units_for(cout), DTYPE_BF16)
+            dyb = ops.to_blocked_now(dy.float().contiguous(), units_for(cout), DTYPE_BF16)
         elif ctx.out_kind == "f32":                 # [N,H,C/4,W,4] fp32 -> [N,H,C/8,W,8] bf16
             dyb = dy.reshape(N, H, cout // 8, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, cout // 8, W, 8)
             dyb = dyb.to(torch.bfloat16).contiguous()
@@ -158,13 +158,13 @@ class _Conv3x3(torch.autograd.Function):
             n_out = (cin + 3) // 4 * 4
             alloc = torch.empty if U * 8 == n_out else torch.zeros
             dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
-            ops.conv3x3_fwd(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
+            ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((cout,), dtype=torch.float32, device=x.device)
             for c0 in range(0, cout, 64):            # the wgrad kernel takes at most 64 output channels a call
                 cb = min(64, cout - c0)
-                ops.conv3x3_wgrad(x, cin, 0, dyb, c0 // 8, cb, 1.0, 0, dw[c0:c0 + cb], db[c0:c0 + cb])
+                ops.conv3x3_wgrad_now(x, cin, 0, dyb, c0 // 8, cb, 1.0, 0, dw[c0:c0 + cb], db[c0:c0 + cb])
         return dx, dw, db, None, None
 
 

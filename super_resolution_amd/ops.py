@@ -508,3 +508,17 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
         check(_lib.lib().sr355_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                          exp_avg_sq.data_ptr(), n, lr, beta1, beta2, eps, weight_decay, step,
                                          _stream()), "sr355_adam_step")
+
+
+def now(op):
+    """The Python body of a registered ``sr355::`` op, callable without the dispatcher.  Inside an
+    ``autograd.Function`` nothing is recorded and the ops only read their tensors' memory, so the per-call
+    bookkeeping of the dispatcher (schema walk, autograd keys, alias checks: several microseconds, paid
+    hundreds of times per training step) buys nothing there.  Falls back to the op itself."""
+    return getattr(op, "_init_fn", op)
+
+
+conv3x3_fwd_now = now(conv3x3_fwd)
+conv3x3_wgrad_now = now(conv3x3_wgrad)
+to_blocked_now = now(to_blocked)
+from_blocked_now = now(from_blocked)
