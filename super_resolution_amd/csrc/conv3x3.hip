@@ -309,6 +309,14 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
         const long long tiles = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
         if (force == 1 || (force != 0 && tiles >= 192)) return launch_conv3x3_ring(a, cin_units, weight_split, stream);
     }
+    if (dtype == SR355_DTYPE_BF16 && (a.cout_pad == 32 || a.cout_pad == 64)) {
+        // Launches that cannot fill the chip (training patches): the LDS-DMA kernel on 4-row tiles, one per
+        // workgroup, instead of the register-staged kernel below (pixel iteration 11.4 -> 10.4 ms);
+        // SR355_SMALL_FINE=0 keeps the register-staged kernel for A/B measurements.
+        static const int small_fine = [] { const char *e = getenv("SR355_SMALL_FINE"); return e ? atoi(e) : 1; }();
+        const long long blocks8 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 7) / 8) * (a.cout_pad / 32);
+        if (small_fine && blocks8 < 512) return launch_conv3x3_fine_small(b, stream);
+    }
     bool wide = (a.cout_pad % 64) == 0;
     if (wide && dtype == SR355_DTYPE_BF16) {
         // too few tiles to give every CU a workgroup: one workgroup per 32 output channels instead of 64

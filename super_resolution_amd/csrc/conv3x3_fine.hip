@@ -78,7 +78,8 @@ struct FineGeo {
     static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
     static_assert(CO <= 64, "bias image is one 256-byte DMA");
     static_assert((R - 2) * KMAX <= 63, "vmcnt field is 6 bits");
-    static_assert(2 * N_MFMA >= N_READS && N_MFMA >= KMAX, "not enough MFMAs to hide the reads / the DMA issue");
+    // (4-row tiles, NB = 1, are for launches that cannot fill the chip: their stage is short on purpose)
+    static_assert(2 * N_MFMA >= N_READS && (N_MFMA >= KMAX || NB == 1), "not enough MFMAs to hide the reads / the DMA issue");
 };
 }  // namespace
 
@@ -429,6 +430,15 @@ int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     static const int force_nb = [] { const char *e = getenv("SR355_NARROW_NB"); return e ? atoi(e) : 0; }();
     if (force_nb == 4 || (force_nb == 0 && tiles16 >= cu)) return launch_fine_inst<1, 4, 2>(b, stream);
     return launch_fine_inst<1, 2, 3>(b, stream);
+}
+
+
+// Small images (a launch of 4-row tiles does not fill the chip): one tile per workgroup, four stages in flight, 32
+// output channels per workgroup so that a 64-channel conv spreads over twice the workgroups.
+int launch_conv3x3_fine_small(const ConvArgs &a, hipStream_t stream) {
+    ConvArgs b = a;
+    b.trace = g_conv_trace;
+    return launch_fine_inst<1, 1, 4>(b, stream);
 }
 
 }  // namespace sr355

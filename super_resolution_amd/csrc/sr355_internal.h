@@ -56,6 +56,7 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
 
 // Ring kernel with a branch-free, MFMA-interleaved stage body; n_stages, n_real_stages and debug must be set.
 int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream);
+int launch_conv3x3_fine_small(const ConvArgs &a, hipStream_t stream);
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
                            int dst_units, int split, hipStream_t stream);
