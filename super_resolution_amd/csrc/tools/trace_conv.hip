@@ -87,6 +87,12 @@ static int mfma_peak() {
     return 0;
 }
 
+// TRACE_SMALL=1: through the shape router (small images take the 4-row, one-tile-per-workgroup instantiation)
+static int launch_traced(const ConvArgs &a, int cin_units, hipStream_t st) {
+    static const bool routed = getenv("TRACE_SMALL") != nullptr;
+    return routed ? launch_conv3x3(a, SR355_DTYPE_BF16, cin_units, 0, st) : launch_conv3x3_ring(a, cin_units, 0, st);
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "mfma")) return mfma_peak();
     const int cin_units = argc > 1 ? atoi(argv[1]) : 24;
@@ -140,7 +146,7 @@ int main(int argc, char **argv) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     for (int i = 0; i < 20; ++i)
-        if (launch_conv3x3_ring(a, cin_units, 0, st)) return 2;
+        if (launch_traced(a, cin_units, st)) return 2;
     CK(hipStreamSynchronize(st));
     CK(hipMemset(trace, 0, 2 * max_wg * 16 * 8));
     hipEvent_t e0, e1;
@@ -148,13 +154,13 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     // a few untraced launches just before, so the traced one starts behind a busy queue as in a forward
     for (int i = 0; i < 3; ++i)
-        if (launch_conv3x3_ring(a, cin_units, 0, st)) return 2;
+        if (launch_traced(a, cin_units, st)) return 2;
     g_conv_trace = trace;
     CK(hipEventRecord(e0, st));
-    if (launch_conv3x3_ring(a, cin_units, 0, st)) return 2;
+    if (launch_traced(a, cin_units, st)) return 2;
     CK(hipEventRecord(e1, st));
     g_conv_trace = nullptr;
-    if (launch_conv3x3_ring(a, cin_units, 0, st)) return 2;
+    if (launch_traced(a, cin_units, st)) return 2;
     CK(hipStreamSynchronize(st));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
