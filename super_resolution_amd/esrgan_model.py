@@ -181,15 +181,21 @@ class GeneratorRRDB(nn.Module):
 
     # -- parameter plumbing ---------------------------------------------------------------
     def conv_modules(self) -> List[nn.Conv2d]:
-        """The convs in state_dict order (the module tree is fixed at construction: walked once)."""
-        mods = self.__dict__.get("_conv_list")
-        if mods is None:
-            mods = [self.conv_first]
-            for rrdb in self.body:
-                for r in (1, 2, 3):
-                    mods.extend(getattr(rrdb, f"rdb{r}")._convs())
-            mods += [self.trunk_conv, self.upconv1, self.upconv2, self.HR_conv, self.conv_last]
-            self.__dict__["_conv_list"] = mods
+        """The convs in state_dict order.  Walked on every call (a submodule may have been replaced) through the
+        ``_modules`` dicts: ``nn.Module.__getattr__`` on 400 names costs more than the rest of a training step's
+        host work on this module."""
+        top = self._modules
+        mods = [top["conv_first"]]
+        for rrdb in top["body"]._modules.values():
+            blocks = rrdb._modules
+            for name in ("rdb1", "rdb2", "rdb3"):
+                convs = blocks[name]._modules
+                mods.append(convs["conv1"])
+                mods.append(convs["conv2"])
+                mods.append(convs["conv3"])
+                mods.append(convs["conv4"])
+                mods.append(convs["conv5"])
+        mods += [top["trunk_conv"], top["upconv1"], top["upconv2"], top["HR_conv"], top["conv_last"]]
         return mods
 
     def conv_parameters(self) -> List[Tensor]:

@@ -134,3 +134,16 @@ def test_conditional_vae_surface():
         net(torch.rand(1, 3, 32, 32))
     with pytest.raises(RuntimeError):
         net.sample(1, torch.rand(1, 3, 32, 32))
+
+
+def test_conv_parameter_list_follows_the_module_tree():
+    """The packing code lists the 702 parameters itself (state_dict order); a replaced submodule or parameter must
+    show up in the next listing, as it does in ``parameters()``."""
+    import torch.nn as nn
+    net = S.GeneratorRRDB(num_blocks=2)
+    assert [id(p) for p in net.conv_parameters()] == [id(p) for p in net.parameters()]
+    net.body[1].rdb2.conv4 = nn.Conv2d(160, 32, 3, 1, 1)
+    net.conv_last.bias = nn.Parameter(torch.zeros(3))
+    assert [id(p) for p in net.conv_parameters()] == [id(p) for p in net.parameters()]
+    assert [k for k, _ in net.named_parameters()] == [f"{n}.{s}" for n, m in net.named_modules()
+                                                       if isinstance(m, nn.Conv2d) for s in ("weight", "bias")]
