@@ -89,6 +89,15 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     constexpr int WAVES = G::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SR355_FSTAMP(0);
+    {
+        // The argument block spans four 64-byte lines and the set-up code below reads it piecemeal, one scalar-cache
+        // miss after the other; touching every line first puts the misses in flight together.
+        typedef __attribute__((address_space(4))) const unsigned kernarg_word;
+        kernarg_word *ka = (kernarg_word *)__builtin_amdgcn_kernarg_segment_ptr();
+        static_assert(sizeof(ConvArgs) > 192 && sizeof(ConvArgs) <= 256, "argument block: four lines");
+        const unsigned k0 = ka[0], k1 = ka[16], k2 = ka[32], k3 = ka[48];
+        asm volatile("" ::"s"(k0), "s"(k1), "s"(k2), "s"(k3));
+    }
 #ifdef SR355_TRACE
     const unsigned long long sclk0_ = __builtin_readcyclecounter();
 #endif
