@@ -132,7 +132,7 @@ def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=Tru
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -165,7 +165,7 @@ def roofline_from(rows):
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r01h_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
+            "traffic_source": "profiles/r01k_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
                               "of this command with --streams 1)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),
