@@ -510,6 +510,11 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
                                          _stream()), "sr355_adam_step")
 
 
+@adam_step.register_fake
+def _(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    return None
+
+
 def now(op):
     """The Python body of a registered ``sr355::`` op, callable without the dispatcher.  Inside an
     ``autograd.Function`` nothing is recorded and the ops only read their tensors' memory, so the per-call

@@ -1,0 +1,83 @@
+"""CPU: every registered ``sr355::`` op has a fake (meta) implementation, and it predicts what the real op returns:
+shapes, dtypes and devices under ``FakeTensorMode`` (what ``torch.compile`` / functionalisation trace through), with
+sizes taken from the C library's own size queries.  No kernel runs; the tensors are fake CUDA tensors."""
+import pytest
+import torch
+from torch._subclasses.fake_tensor import FakeTensorMode
+
+import super_resolution_amd as S  # noqa: F401  (registers the ops)
+from super_resolution_amd import ops
+from super_resolution_amd._lib import DTYPE_BF16, DTYPE_F32, lib
+
+CFG = [3, 3, 64, 2, 32, DTYPE_BF16, 1, 1]          # two RRDBs, bf16, weight residue on the HR side, fp32 carriers
+N, H, W = 2, 9, 33
+
+OPS = ("to_blocked", "from_blocked", "pack_weight", "conv3x3_fwd", "pack_weight_transposed", "pool2x2_sum",
+       "conv3x3_wgrad", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
+       "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step")
+
+
+def test_every_op_is_registered_with_a_fake():
+    for name in OPS:
+        op = getattr(torch.ops.sr355, name)
+        assert op.default._schema.name == f"sr355::{name}"
+        assert getattr(ops, name)._abstract_fn is not None, f"{name} has no fake implementation"
+
+
+def cuda(*shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device="cuda")
+
+
+def test_layout_and_conv_ops_under_fake_mode():
+    with FakeTensorMode():
+        x = cuda(N, 20, H, W)
+        for dtype, tdt, per_unit in ((DTYPE_BF16, torch.bfloat16, 8), (DTYPE_F32, torch.float32, 4)):
+            b = torch.ops.sr355.to_blocked(x, 6, dtype)
+            assert b.shape == (N, H, 6, W, per_unit) and b.dtype == tdt and b.device.type == "cuda"
+            y = torch.ops.sr355.from_blocked(b, 0, 20)
+            assert y.shape == (N, 20, H, W) and y.dtype == torch.float32
+        w, bias = cuda(32, 20, 3, 3), cuda(32)
+        for split in (0, 1):
+            wp, bp = torch.ops.sr355.pack_weight(w, bias, DTYPE_BF16, split)
+            assert wp.dtype == torch.uint8 and wp.numel() == lib().sr355_packed_weight_bytes(32, 20, DTYPE_BF16, split)
+            assert bp.shape == (32,) and bp.dtype == torch.float32
+        b = torch.ops.sr355.to_blocked(x, 8, DTYPE_BF16)
+        wp, bp = torch.ops.sr355.pack_weight(w, bias, DTYPE_BF16)
+        assert torch.ops.sr355.conv3x3_fwd(b, 4, wp, bp, 32, 0.2, 0, None, 0.0, None, 0.0, b, 4, None, None) is None
+        dw, db = cuda(32, 20, 3, 3), cuda(32)
+        assert torch.ops.sr355.conv3x3_wgrad(b, 20, 0, b, 4, 32, 1.0, 0, dw, db) is None
+
+
+def test_generator_ops_under_fake_mode():
+    sizes = {
+        "packed": ops.generator_packed_bytes(CFG), "ws": ops.generator_workspace_bytes(CFG, N, H, W),
+        "saved": ops.generator_saved_bytes(CFG, N, H, W), "tws": ops.generator_train_workspace_bytes(CFG, N, H, W),
+        "bws": ops.generator_bwd_workspace_bytes(CFG, N, H, W), "grads": ops.generator_grads_floats(CFG),
+    }
+    assert all(v > 0 for v in sizes.values()), sizes
+    net = S.GeneratorRRDB(num_blocks=2)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert sizes["grads"] == n_params                      # one fp32 slot per parameter, state_dict order
+    with FakeTensorMode():
+        weights = [cuda(*c.weight.shape) for c in net.conv_modules()]
+        biases = [cuda(*c.bias.shape) for c in net.conv_modules()]
+        packed = torch.ops.sr355.generator_pack(weights, biases, CFG)
+        assert packed.dtype == torch.uint8 and packed.numel() == sizes["packed"]
+        x = cuda(N, 3, H, W)
+        out = torch.ops.sr355.generator_forward(x, packed, cuda(sizes["ws"], dtype=torch.uint8), CFG)
+        assert out.shape == (N, 3, 4 * H, 4 * W) and out.dtype == torch.float32
+        img = cuda(N, H, W, 3, dtype=torch.uint8)
+        out8 = torch.ops.sr355.generator_forward_u8(img, packed, cuda(sizes["ws"], dtype=torch.uint8), CFG)
+        assert out8.shape == (N, 4 * H, 4 * W, 3) and out8.dtype == torch.uint8
+        saved = cuda(sizes["saved"], dtype=torch.uint8)
+        out = torch.ops.sr355.generator_forward_train(x, packed, saved, cuda(sizes["tws"], dtype=torch.uint8), CFG)
+        assert out.shape == (N, 3, 4 * H, 4 * W)
+        pb = torch.ops.sr355.generator_pack_bwd(weights, CFG)
+        assert pb.dtype == torch.uint8 and pb.numel() > 0
+        for need_x in (True, False):
+            flat, gin = torch.ops.sr355.generator_backward(out, pb, saved, cuda(sizes["bws"], dtype=torch.uint8), CFG,
+                                                           H, W, need_x)
+            assert flat.shape == (n_params,) and flat.dtype == torch.float32
+            assert gin.shape == ((N, 3, H, W) if need_x else (0,))
+        p = cuda(n_params)
+        assert torch.ops.sr355.adam_step(p, p, p, p, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1) is None
