@@ -36,18 +36,22 @@ def _conv(cin: int, cout: int) -> nn.Conv2d:
 
 
 class _PackCache:
-    """Packed copies of a module's conv parameters, rebuilt when any parameter changes."""
+    """Packed copies of a module's conv parameters, rebuilt when any parameter changes.  One entry per (device,
+    arithmetic): ``nn.DataParallel`` replicas share this object (``replicate`` copies a module's ``__dict__``
+    shallowly) and call it from one thread per device, so an entry is read and replaced as a whole and a caller
+    only ever returns the pack it looked up or built itself."""
 
     def __init__(self) -> None:
-        self.key = None
-        self.value = None
+        self.entries: Dict[Tuple, Tuple] = {}
 
-    def get(self, params: List[Tensor], dtype: int, builder):
-        key = (dtype, params[0].device, tuple(map(_VERSION_OF, params)), tuple(map(Tensor.data_ptr, params)))
-        if key != self.key:
-            self.value = builder()
-            self.key = key
-        return self.value
+    def get(self, params: List[Tensor], dtype, builder):
+        slot = (dtype, params[0].device)
+        key = (tuple(map(_VERSION_OF, params)), tuple(map(Tensor.data_ptr, params)))
+        entry = self.entries.get(slot)
+        if entry is None or entry[0] != key:
+            entry = (key, builder())
+            self.entries[slot] = entry
+        return entry[1]
 
 
 class ResidualDenseBlock(nn.Module):
@@ -177,7 +181,7 @@ class GeneratorRRDB(nn.Module):
         self._cache = _PackCache()
         self._cache_inf = _PackCache()
         self._cache_bwd = _PackCache()
-        self._workspace: Optional[Tensor] = None
+        self._workspace: Optional[Dict] = None
 
     # -- parameter plumbing ---------------------------------------------------------------
     def conv_modules(self) -> List[nn.Conv2d]:
@@ -225,12 +229,17 @@ class GeneratorRRDB(nn.Module):
         return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack_now(params[0::2], params[1::2], cfg))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:
+        """Scratch memory of a no-grad forward, kept per device and grown on demand."""
         need = ops.generator_workspace_bytes(self.cfg(), N, H, W)
-        ws = self._workspace
-        if ws is None or ws.numel() < need or ws.device != device:
-            self._workspace = None          # release before growing
+        held = self._workspace
+        if held is None:
+            held = self._workspace = {}
+        ws = held.get(device)
+        if ws is None or ws.numel() < need:
+            held.pop(device, None)          # release before growing
+            ws = None
             ws = torch.empty(need, dtype=torch.uint8, device=device)
-            self._workspace = ws
+            held[device] = ws
         return ws
 
     def packed_bwd_parameters(self) -> Tensor:
