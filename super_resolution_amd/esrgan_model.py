@@ -204,12 +204,13 @@ class GeneratorRRDB(nn.Module):
 
     def conv_parameters(self) -> List[Tensor]:
         """weight, bias of every conv in state_dict order, read from the modules on every call (a parameter may
-        have been replaced since the last one)."""
+        have been replaced since the last one).  An ``nn.DataParallel`` replica holds them as plain attributes."""
         out = []
         for c in self.conv_modules():
             d = c._parameters
-            out.append(d["weight"])
-            out.append(d["bias"])
+            w, b = d.get("weight"), d.get("bias")
+            out.append(w if w is not None else c.weight)
+            out.append(b if b is not None else c.bias)
         return out
 
     def cfg(self, inference: bool = False) -> List[int]:
@@ -281,10 +282,16 @@ class GeneratorRRDB(nn.Module):
         return out[0] if single else out
 
 
+def _writes_grads_itself(module: "GeneratorRRDB", params: List[Tensor]) -> bool:
+    """``direct_grads`` applies to a module that owns its parameters.  In an ``nn.DataParallel`` replica they are
+    outputs of a broadcast (not leaves): their gradients have to flow back through autograd to the originals."""
+    return bool(module.direct_grads and params and params[0].is_leaf and params[-1].is_leaf)
+
+
 def _graph_params(module: "GeneratorRRDB", params: List[Tensor]) -> List[Tensor]:
     """The parameters the autograd node takes as inputs: all of them, or with ``direct_grads`` one trainable
     parameter that merely ties the node into the graph (the backward then fills ``.grad`` itself)."""
-    if not module.direct_grads:
+    if not _writes_grads_itself(module, params):
         return params
     for p in params:
         if p.requires_grad:
@@ -307,7 +314,7 @@ class _GeneratorFunction(torch.autograd.Function):
         ctx.module, ctx.saved, ctx.lr_shape, ctx.reducer = module, saved, (N, H, W), reducer
         ctx.need_x = x.requires_grad
         ctx.n_graph_params = len(params)
-        ctx.direct = module.direct_grads
+        ctx.direct = _writes_grads_itself(module, module.conv_parameters())
         return out
 
     @staticmethod

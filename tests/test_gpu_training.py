@@ -343,3 +343,23 @@ def test_data_parallel_backward_two_ranks_one_gpu():
     assert ret["buckets"] >= 2
     assert ret["worst"] < 1e-5, ret["worst"]     # same kernels, same order: only the mean differs in rounding
     assert ret["losses_finite"] and ret["replicas_equal"]
+
+
+def test_data_parallel_replica_routes_gradients_through_autograd():
+    """esrgan/train.py:108-111 wraps the generator in nn.DataParallel: a replica's parameters are broadcast outputs,
+    not leaves, so the backward must hand their gradients to autograd (which carries them back to the originals)
+    instead of writing ``.grad`` itself."""
+    from torch.nn.parallel import replicate
+    torch.manual_seed(3)
+    net = S.GeneratorRRDB(num_blocks=1).to(DEV)
+    ref = S.GeneratorRRDB(num_blocks=1).to(DEV)
+    ref.load_state_dict(net.state_dict())
+    x = torch.rand(2, 3, 8, 8, generator=torch.Generator().manual_seed(4)).to(DEV)
+    r = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+    replica = replicate(net, [0])[0]
+    assert not replica.conv_first.weight.is_leaf
+    (replica(x) * r).sum().backward()
+    (ref(x) * r).sum().backward()
+    for (name, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert p.grad is not None, name
+        assert torch.equal(p.grad, q.grad), name
