@@ -280,6 +280,28 @@ def test_generator_full_depth_against_reference_vector(golden, precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 3, 1, 1), (2, 3, 1, 5), (1, 3, 3, 2), (5, 3, 33, 1)])
+def test_generator_smallest_images_match_oracle(precision, shape):
+    """Any H, W >= 1 (the forward contract of the reference module): images smaller than one tile, one pixel wide
+    or high, in inference and in a recorded forward + backward."""
+    sd = O.center_outputs(O.make_generator_state(23, num_blocks=2))
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(24))
+    net = load_net(S.GeneratorRRDB(num_blocks=2, precision=precision), sd)
+    with torch.no_grad():
+        out = net(x.to(DEV)).cpu()
+        ref = O.generator_forward(sd, x)
+    assert out.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+    gate(out, ref, precision)
+    if precision == "bf16":
+        xg = x.to(DEV).requires_grad_(True)
+        rec = net(xg)
+        gate(rec.detach().cpu(), ref, precision)
+        rec.sum().backward()
+        assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_generator_ragged_batch_matches_oracle(precision):
     sd = O.center_outputs(O.make_generator_state(21, num_blocks=3))
     x = torch.rand(3, 3, 21, 45, generator=torch.Generator().manual_seed(22))
