@@ -463,3 +463,46 @@ def test_fp16_hr_side_saturates_instead_of_overflowing():
         wide = load_net(S.GeneratorRRDB(num_blocks=1, hr_f16=False), sd)(x)     # bf16 has the range
     assert torch.isfinite(out).all() and torch.isfinite(wide).all()
     assert out.abs().max().item() < wide.abs().max().item()                    # saturated, not equal
+
+
+def test_entry_points_reject_undersized_buffers_with_a_message():
+    """Error convention of the boundary: a RuntimeError carrying the library's message, raised before any kernel is
+    launched, for buffers that are too small for the declared geometry or slices that leave the buffer."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 20, 9, 33, generator=g).to(DEV)
+    b = ops.to_blocked(x, 8, DTYPE_BF16)
+    w, bias = (torch.rand(32, 20, 3, 3, generator=g) - 0.5).to(DEV), torch.rand(32, generator=g).to(DEV)
+    wp, bp = ops.pack_weight(w, bias, DTYPE_BF16)
+    keep = b.clone()
+
+    def conv(**kw):
+        a = dict(cin_units=4, wp=wp, cout=32, out_act=b, off=4, f32=None, nchw=None)
+        a.update(kw)
+        ops.conv3x3_fwd(b, a["cin_units"], a["wp"], bp, a["cout"], 0.2, 0, None, 0.0, None, 0.0, a["out_act"], a["off"],
+                        a["f32"], a["nchw"])
+
+    with pytest.raises(RuntimeError, match="activation output geometry"):
+        conv(off=6)                                                   # units [6, 10) of an 8-unit buffer
+    with pytest.raises(RuntimeError, match="packed weights"):
+        conv(cin_units=8)                                             # the pack holds 4 units of input channels
+    with pytest.raises(RuntimeError, match="cin_units"):
+        conv(cin_units=10)                                            # more than the buffer has
+    with pytest.raises(RuntimeError, match="does not match"):
+        conv(out_act=None, nchw=torch.empty(2, 32, 9, 32, device=DEV))   # another image width than the input's
+    with pytest.raises(RuntimeError, match="NCHW output too small"):
+        conv(out_act=None, nchw=torch.empty(2, 31, 9, 33, device=DEV))
+    with pytest.raises(RuntimeError, match="too small"):
+        conv(out_act=None, f32=torch.empty(2, 9, 7, 33, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="no output"):
+        conv(out_act=None)
+    assert torch.equal(b, keep)                                       # nothing ran
+    net = S.GeneratorRRDB(num_blocks=1).to(DEV)
+    cfg = net.cfg(True)
+    packed = net.packed_parameters(True)
+    xin = torch.rand(1, 3, 8, 8, generator=g).to(DEV)
+    need = ops.generator_workspace_bytes(cfg, 1, 8, 8)
+    with pytest.raises(RuntimeError, match="workspace"):
+        ops.generator_forward(xin, packed, torch.empty(need - 256, dtype=torch.uint8, device=DEV), cfg)
+    with pytest.raises(RuntimeError, match="pack"):
+        ops.generator_forward(xin, packed[:-256], torch.empty(need, dtype=torch.uint8, device=DEV), cfg)
+    conv()                                                            # and the library still works afterwards
