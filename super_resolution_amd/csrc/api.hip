@@ -222,8 +222,10 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
         const size_t out_img = px * (size_t)(p->out_act_dev ? p->out_units : 0) * 16;
         const size_t f32_img = px * (size_t)p->cout * 4;
         const size_t ra_img = px * (size_t)(p->res_act_dev ? p->res_act_units : 0) * 16;
-        if (out_img >= ((size_t)1 << 31) || f32_img >= ((size_t)1 << 31) || ra_img >= ((size_t)1 << 31)) {
-            set_error("conv3x3_fwd: one output / residual image exceeds 2 GiB; the kernel indexes an image with 31 bits");
+        const size_t mk_img = px * (size_t)(p->mask_dev ? p->mask_units : 0) * 16;
+        if (out_img >= ((size_t)1 << 31) || f32_img >= ((size_t)1 << 31) || ra_img >= ((size_t)1 << 31) ||
+            mk_img >= ((size_t)1 << 31)) {
+            set_error("conv3x3_fwd: one output / residual / mask image exceeds 2 GiB; the kernel indexes an image with 31 bits");
             return SR355_ERR_UNSUPPORTED;
         }
     }

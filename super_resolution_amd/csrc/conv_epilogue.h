@@ -109,12 +109,12 @@ __device__ __forceinline__ void conv_epilogue_quad(const ConvArgs &a, float (&v)
 // ---- whole-tile epilogue of the ring kernels (bf16 path) ------------------------------------------------------
 // The per-quad form above recomputes 64-bit addresses for every quad and keeps each residual load next to the store
 // that depends on it, so a wave walks through its 16 quads one memory round trip at a time.  For the common shape
-// (no mask, no NCHW / uint8 output, whole 32-channel blocks) this form addresses through buffer descriptors of the
+// (no NCHW / uint8 output, whole 32-channel blocks) this form addresses through buffer descriptors of the
 // tile's image — one 32-bit lane offset per output row, the unit step in the scalar offset — issues the residual
 // loads of four quads together, and drops lanes outside the image by an out-of-range offset instead of a branch.
 // Same arithmetic, in the same order, as conv_epilogue_quad.
 __device__ __forceinline__ bool conv_epilogue_tile_ok(const ConvArgs &a) {
-    return !a.mask_act && !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0;
+    return !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0;
 }
 
 template <int MB, int NB>
@@ -134,21 +134,28 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16
     const size_t f32_img = (size_t)H * W * a.f32_units * 16;
     const __amdgpu_buffer_rsrc_t rs_act = rsrc(a.out_act, (size_t)H * W * a.out_units * 16);
     const __amdgpu_buffer_rsrc_t rs_ra = rsrc(a.res_act, (size_t)H * W * a.res_act_units * 16);
+    const __amdgpu_buffer_rsrc_t rs_mk = rsrc(a.mask_act, (size_t)H * W * a.mask_units * 16);
     const __amdgpu_buffer_rsrc_t rs_r1 = rsrc(a.res1, f32_img);
     const __amdgpu_buffer_rsrc_t rs_r2 = rsrc(a.res2, f32_img);
     const __amdgpu_buffer_rsrc_t rs_f32 = rsrc(a.out_f32, f32_img);
-    const float slope = a.slope;
+    const float slope = a.slope, mask_slope = a.mask_slope;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int y = y0 + nb;
         const bool ok = live && x < W && y < H;
         const int vo_act = ok ? ((y * a.out_units + a.out_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
         const int vo_ra = ok ? ((y * a.res_act_units + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+        const int vo_mk = ok ? ((y * a.mask_units + a.mask_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
         const int vo_f = ok ? ((y * a.f32_units + (cb_co >> 2) + h) * W + x) * 16 : OOB;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            epi_v2u ra[4];
+            epi_v2u ra[4], mk[4];
             epi_v4u r1[4], r2[4];
+            if (a.mask_act) {   // sign gate of a data gradient: the saved activation at the output position
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mk[q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo_mk, (mb * 4 + q) * wstep, 0);
+            }
             if (a.res_act) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -174,6 +181,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16
                 for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+                if (a.mask_act) {
+                    const epi_bf16x4 mv = __builtin_bit_cast(epi_bf16x4, mk[q]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (float)mv[j] > 0.f ? v[j] : v[j] * mask_slope;
+                }
                 if (a.res_act) {
                     const epi_bf16x4 rv = __builtin_bit_cast(epi_bf16x4, ra[q]);
 #pragma unroll
