@@ -162,9 +162,7 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-            for c0 in range(0, cout, 64):            # the wgrad kernel takes at most 64 output channels a call
-                cb = min(64, cout - c0)
-                ops.conv3x3_wgrad_now(x, cin, 0, dyb, c0 // 8, cb, 1.0, 0, dw[c0:c0 + cb], db[c0:c0 + cb])
+            ops.conv3x3_wgrad_all(x, cin, dyb, cout, dw, db)     # 64 output channels a kernel call, looped inside
         return dx, dw, db, None, None
 
 

@@ -256,6 +256,38 @@ def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
     return None
 
 
+def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor) -> None:
+    """Weight / bias gradient of a conv with any number of output channels: ``sr355_conv3x3_wgrad`` takes at most 64
+    of them a call, so this walks ``dy`` in 64-channel slices — one argument block, one workspace and one device
+    context for all of them (a 512-channel layer is eight calls; built per call they cost more host time than
+    the kernels take)."""
+    _need_cuda(in_buf, dy, dw, db)
+    if in_buf.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        raise RuntimeError("conv3x3_wgrad runs on bf16 activations")
+    if not (dw.is_contiguous() and db.is_contiguous()) or dw.shape[0] != cout or db.numel() != cout:
+        raise RuntimeError("conv3x3_wgrad_all: dw [cout, cin, 3, 3] and db [cout] must be contiguous fp32 tensors")
+    L = _lib.lib()
+    N, H, _U, W, _c = (int(v) for v in dy.shape)
+    a = WgradArgs()
+    a.N, a.H, a.W, a.upsample = N, H, W, 0
+    a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
+    a.dy_dev, a.dy_bytes, a.dy_units = dy.data_ptr(), _nbytes(dy), int(dy.shape[2])
+    a.scale, a.accumulate = 1.0, 0
+    need = L.sr355_wgrad_workspace_bytes(min(cout, 64), cin, N, H, W)
+    if need == 0:
+        raise RuntimeError("conv3x3_wgrad: unsupported shape")
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device)      # calls run in stream order: one workspace serves all
+    a.workspace_dev, a.workspace_bytes = ws.data_ptr(), need
+    dw_ptr, db_ptr, row = dw.data_ptr(), db.data_ptr(), int(cin) * 9 * 4
+    stream = _stream()
+    with torch.cuda.device(dy.device):
+        for c0 in range(0, cout, 64):
+            cb = min(64, cout - c0)
+            a.dy_unit_off, a.cout = c0 // 8, cb
+            a.dw_dev, a.dw_bytes, a.db_dev = dw_ptr + c0 * row, cb * row, db_ptr + c0 * 4
+            check(L.sr355_conv3x3_wgrad(C.byref(a), stream), "sr355_conv3x3_wgrad")
+
+
 # ------------------------------------------------------------------------------------
 def make_cfg(cfg: List[int]) -> GeneratorCfg:
     """cfg = [in_channels, out_channels, num_features, num_blocks, growth_channels, dtype, hr_split] and optionally
