@@ -6,6 +6,7 @@ HIP kernels.  Blocked activation tensors have shape ``[N, H, U, W, c]`` with ``c
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import List, Optional, Tuple
 
@@ -21,7 +22,18 @@ UNIT_CHANNELS = {DTYPE_BF16: 8, DTYPE_F32: 4}
 
 
 def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device, as the C ABI takes it (the raw handle, without building a
+    ``torch.cuda.Stream`` object around it: this runs once per kernel call)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+_SAME_DEVICE = contextlib.nullcontext()
+
+
+def _on(device: torch.device):
+    """Context in which ``device`` is the current device; nothing to enter when it already is."""
+    idx = device.index
+    return _SAME_DEVICE if idx is None or idx == torch._C._cuda_getDevice() else torch.cuda.device(device)
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
@@ -52,7 +64,7 @@ def to_blocked(x: Tensor, units: int, dtype: int, split: int = 0) -> Tensor:
         raise RuntimeError("to_blocked expects an fp32 NCHW tensor")
     N, Cc, H, W = x.shape
     out = torch.empty((N, H, units, W, UNIT_CHANNELS[dtype]), dtype=_TORCH_DTYPE[dtype], device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.lib().sr355_nchw_to_blocked(x.data_ptr(), N, Cc, H, W, dtype, out.data_ptr(), units, split,
                                                _nbytes(out), _stream()), "sr355_nchw_to_blocked")
     return out
@@ -70,7 +82,7 @@ def from_blocked(buf: Tensor, unit_off: int, channels: int) -> Tensor:
     _need_cuda(buf)
     N, H, U, W, _c = buf.shape
     out = torch.empty((N, channels, H, W), dtype=torch.float32, device=buf.device)
-    with torch.cuda.device(buf.device):
+    with _on(buf.device):
         check(_lib.lib().sr355_blocked_to_nchw(buf.data_ptr(), U, unit_off, _CODE[buf.dtype], N, channels, H, W,
                                                out.data_ptr(), _nbytes(out), _stream()), "sr355_blocked_to_nchw")
     return out
@@ -96,7 +108,7 @@ def pack_weight(w: Tensor, bias: Tensor, dtype: int, split: int = 0) -> Tuple[Te
         check(-1, "sr355_packed_weight_bytes")
     wp = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     bp = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         check(L.sr355_pack_weight(w.data_ptr(), bias.data_ptr(), cout, cin, dtype, split, wp.data_ptr(), nbytes,
                                   bp.data_ptr(), _stream()), "sr355_pack_weight")
     return wp, bp
@@ -178,7 +190,7 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
     a = conv_args(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale,
                   res2, res2_scale, out_act, out_unit_off, out_f32, out_nchw, weight_split, mask, mask_unit_off,
                   mask_slope, res1_weight, res2_weight)
-    with torch.cuda.device(in_buf.device):
+    with _on(in_buf.device):
         launch_conv(a)
 
 
@@ -196,7 +208,7 @@ def pack_weight_transposed(w: Tensor, ci_lo: int, n_out: int, scale: float, w_pa
     """Write the data-gradient (transposed, tap-mirrored) form of forward weight ``w`` into input units
     [unit_off, ...) of ``w_packed``; see sr355_pack_weight_transposed in include/sr355.h."""
     _need_cuda(w, w_packed)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         check(_lib.lib().sr355_pack_weight_transposed(w.data_ptr(), int(w.shape[0]), int(w.shape[1]), ci_lo, n_out,
                                                       dtype, float(scale), w_packed.data_ptr(), packed_units,
                                                       unit_off, _nbytes(w_packed), _stream()),
@@ -214,7 +226,7 @@ def pool2x2_sum(x: Tensor, mask: Optional[Tensor], mask_unit_off: int, mask_slop
     """Adjoint of nearest x2 upsampling on a blocked tensor [N,2H,U,2W,c], optionally sign-gated."""
     _need_cuda(x, mask, out_f32, out_act)
     N, H2, U, W2, _c = x.shape
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.lib().sr355_pool2x2_sum(
             x.data_ptr(), _nbytes(x), N, H2 // 2, W2 // 2, U, _CODE[x.dtype],
             _ptr(mask), _nbytes(mask), int(mask.shape[2]) if mask is not None else 0, mask_unit_off, float(mask_slope),
@@ -247,7 +259,7 @@ def conv3x3_wgrad(in_buf: Tensor, cin: int, upsample: int, dy: Tensor, dy_unit_o
         raise RuntimeError("conv3x3_wgrad: unsupported shape")
     ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
     a.workspace_dev, a.workspace_bytes = ws.data_ptr(), need
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         check(L.sr355_conv3x3_wgrad(C.byref(a), _stream()), "sr355_conv3x3_wgrad")
 
 
@@ -279,8 +291,8 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
     ws = torch.empty(need, dtype=torch.uint8, device=dy.device)      # calls run in stream order: one workspace serves all
     a.workspace_dev, a.workspace_bytes = ws.data_ptr(), need
     dw_ptr, db_ptr, row = dw.data_ptr(), db.data_ptr(), int(cin) * 9 * 4
-    stream = _stream()
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
+        stream = _stream()
         for c0 in range(0, cout, 64):
             cb = min(64, cout - c0)
             a.dy_unit_off, a.cout = c0 // 8, cb
@@ -330,7 +342,7 @@ def generator_pack_now(weights: List[Tensor], biases: List[Tensor], cfg: List[in
     for w in weights + biases:
         if w.dtype != torch.float32:
             raise RuntimeError("generator_pack expects fp32 parameters")
-    with torch.cuda.device(blob.device):
+    with _on(blob.device):
         check(L.sr355_generator_pack(C.byref(c), wp, bp, n, blob.data_ptr(), nbytes, _stream()),
               "sr355_generator_pack")
     return blob
@@ -358,7 +370,7 @@ def generator_forward(x: Tensor, packed: Tensor, workspace: Tensor, cfg: List[in
     if Cin != c.in_channels:
         raise RuntimeError(f"generator_forward: input has {Cin} channels, model expects {c.in_channels}")
     out = torch.empty((N, c.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.lib().sr355_generator_forward(C.byref(c), packed.data_ptr(), _nbytes(packed), x.data_ptr(),
                                                  out.data_ptr(), N, H, W, workspace.data_ptr(),
                                                  _nbytes(workspace), _stream()), "sr355_generator_forward")
@@ -383,7 +395,7 @@ def generator_forward_u8(image: Tensor, packed: Tensor, workspace: Tensor, cfg: 
     if Cin != c.in_channels:
         raise RuntimeError(f"generator_forward_u8: image has {Cin} channels, model expects {c.in_channels}")
     out = torch.empty((N, 4 * H, 4 * W, c.out_channels), dtype=torch.uint8, device=image.device)
-    with torch.cuda.device(image.device):
+    with _on(image.device):
         check(_lib.lib().sr355_generator_forward_u8(C.byref(c), packed.data_ptr(), _nbytes(packed), image.data_ptr(),
                                                     out.data_ptr(), N, H, W, workspace.data_ptr(),
                                                     _nbytes(workspace), _stream()), "sr355_generator_forward_u8")
@@ -429,7 +441,7 @@ def generator_forward_train(x: Tensor, packed: Tensor, saved: Tensor, workspace:
     c = make_cfg(cfg)
     N, _cin, H, W = (int(v) for v in x.shape)
     out = torch.empty((N, c.out_channels, 4 * H, 4 * W), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(_lib.lib().sr355_generator_forward_train(C.byref(c), packed.data_ptr(), _nbytes(packed), x.data_ptr(),
                                                        out.data_ptr(), N, H, W, saved.data_ptr(), _nbytes(saved),
                                                        workspace.data_ptr(), _nbytes(workspace), _stream()),
@@ -454,7 +466,7 @@ def generator_pack_bwd_now(weights: List[Tensor], cfg: List[int]) -> Tensor:
     blob = torch.empty(nbytes, dtype=torch.uint8, device=weights[0].device)
     n = len(weights)
     wp = (C.c_void_p * n)(*[w.data_ptr() for w in weights])
-    with torch.cuda.device(blob.device):
+    with _on(blob.device):
         check(L.sr355_generator_pack_bwd(C.byref(c), wp, n, blob.data_ptr(), nbytes, _stream()),
               "sr355_generator_pack_bwd")
     return blob
@@ -486,7 +498,7 @@ def generator_backward(grad_out: Tensor, packed_bwd: Tensor, saved: Tensor, work
     grads = torch.empty(nfl, dtype=torch.float32, device=grad_out.device)
     gin = (torch.empty((N, c.in_channels, H, W), dtype=torch.float32, device=grad_out.device)
            if need_input_grad else torch.empty(0, dtype=torch.float32, device=grad_out.device))
-    with torch.cuda.device(grad_out.device):
+    with _on(grad_out.device):
         check(L.sr355_generator_backward(C.byref(c), packed_bwd.data_ptr(), _nbytes(packed_bwd), saved.data_ptr(),
                                          _nbytes(saved), grad_out.data_ptr(), grads.data_ptr(), nfl,
                                          gin.data_ptr() if need_input_grad else None, N, H, W,
@@ -512,7 +524,7 @@ def generator_backward_range(grad_out: Tensor, packed_bwd: Tensor, saved: Tensor
     phase writes the gradients of its own convs into the flat ``grads`` buffer."""
     _need_cuda(grad_out, packed_bwd, saved, workspace, grads, grad_in)
     c = make_cfg(cfg)
-    with torch.cuda.device(grad_out.device):
+    with _on(grad_out.device):
         check(_lib.lib().sr355_generator_backward_range(
             C.byref(c), packed_bwd.data_ptr(), _nbytes(packed_bwd), saved.data_ptr(), _nbytes(saved),
             grad_out.data_ptr(), grads.data_ptr(), grads.numel(), _ptr(grad_in), int(grad_out.shape[0]),
@@ -536,7 +548,7 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     for t in (param, grad, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
             raise RuntimeError("adam_step expects four contiguous fp32 tensors of one length")
-    with torch.cuda.device(param.device):
+    with _on(param.device):
         check(_lib.lib().sr355_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                          exp_avg_sq.data_ptr(), n, lr, beta1, beta2, eps, weight_decay, step,
                                          _stream()), "sr355_adam_step")
