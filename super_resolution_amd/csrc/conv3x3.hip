@@ -317,6 +317,13 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
         const long long blocks8 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 7) / 8) * (a.cout_pad / 32);
         if (small_fine && blocks8 < 512) return launch_conv3x3_fine_small(b, stream);
     }
+    if (dtype == SR355_DTYPE_BF16 && a.cout_pad > 64 && (a.cout_pad % 64) == 0 && !a.f16_in) {
+        // More than 64 output channels (discriminator, VGG19, sub-pixel convs): the LDS-DMA kernel with one grid row
+        // per 64-channel block, at any image size (adversarial iteration 23.5 -> 22.5 ms); SR355_WIDE_FINE=0 keeps
+        // the register-staged kernel for A/B measurements.
+        static const int wide_fine = [] { const char *e = getenv("SR355_WIDE_FINE"); return e ? atoi(e) : 1; }();
+        if (wide_fine) return launch_conv3x3_ring(a, cin_units, weight_split, stream);
+    }
     bool wide = (a.cout_pad % 64) == 0;
     if (wide && dtype == SR355_DTYPE_BF16) {
         // too few tiles to give every CU a workgroup: one workgroup per 32 output channels instead of 64
