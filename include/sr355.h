@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 8
+#define SR355_ABI_VERSION 9
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -171,6 +171,17 @@ typedef struct sr355_wgrad_args {
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
 int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
+
+/* sr355_conv3x3_wgrad without a workspace: the per-workgroup partial slabs go to a static device array of the
+ * library (SR355_STATIC_SCRATCH_BYTES per GPU, held until the process ends); args->workspace_dev / workspace_bytes
+ * are ignored, and the call makes no hipMalloc / hipFree or any other allocating call.  No counterpart in the
+ * reference: it is for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation).  Shapes whose sr355_wgrad_workspace_bytes() exceeds SR355_STATIC_SCRATCH_BYTES are
+ * rejected with SR355_ERR_INVALID.  All calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (two streams, two threads) race; calls on one stream are ordered.  Results are bit-identical to
+ * sr355_conv3x3_wgrad's. */
+#define SR355_STATIC_SCRATCH_BYTES (16u << 20)
+int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *args, void *stream);
 
 /* ---- whole generator (GeneratorRRDB.forward, esrgan_model.py:55-62) ---- */
 typedef struct sr355_generator_cfg {

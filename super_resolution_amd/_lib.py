@@ -16,8 +16,9 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
+STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
 TRUNK_RRDB = 2   # sr355_generator_cfg.trunk_fp32: fp32 carriers for the RRDB / global skips only (inference)
 HR_F16 = 2       # sr355_generator_cfg.hr_split: HR-side convs in fp16 (inference)
@@ -29,6 +30,7 @@ EXPORTS = (
     "sr355_packed_weight_bytes", "sr355_pack_weight",
     "sr355_conv3x3_fwd",
     "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
+    "sr355_conv3x3_wgrad_static",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
     "sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes", "sr355_generator_forward_train",
@@ -125,6 +127,7 @@ def lib() -> C.CDLL:
     L.sr355_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
     L.sr355_wgrad_workspace_bytes.restype = sz
     L.sr355_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
+    L.sr355_conv3x3_wgrad_static.argtypes = [C.POINTER(WgradArgs), vp]
     L.sr355_generator_num_convs.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.restype = sz

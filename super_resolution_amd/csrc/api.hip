@@ -379,39 +379,60 @@ size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
     return wgrad_workspace_bytes(cout, cin, N, H, W);
 }
 
-int sr355_conv3x3_wgrad(const sr355_wgrad_args *p, void *stream) {
+// Argument checks shared by the two weight-gradient entry points; `ws_bytes` is the scratch the caller has.
+static int wgrad_checks(const char *who, const sr355_wgrad_args *p, const void *ws, size_t ws_bytes) {
     if (!p) {
-        set_error("conv3x3_wgrad: args is null");
+        set_error("%s: args is null", who);
         return SR355_ERR_INVALID;
     }
     if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || p->cout > 64 || p->cin < 1 ||
         (p->upsample != 0 && p->upsample != 1) || (p->upsample && ((p->H | p->W) & 1))) {
-        set_error("conv3x3_wgrad: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d", p->N, p->H, p->W, p->cout,
+        set_error("%s: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d", who, p->N, p->H, p->W, p->cout,
                   p->cin, p->upsample);
         return SR355_ERR_INVALID;
     }
     const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
     const size_t in_img = (size_t)Hin * p->in_units * Win * 16, dy_img = (size_t)p->H * p->dy_units * p->W * 16;
     if (in_img >= ((size_t)1 << 31) || dy_img >= ((size_t)1 << 31)) {
-        set_error("conv3x3_wgrad: one image exceeds the 31-bit offsets of the kernel");
+        set_error("%s: one image exceeds the 31-bit offsets of the kernel", who);
         return SR355_ERR_UNSUPPORTED;
     }
     if (!p->in_dev || !aligned16(p->in_dev) || p->in_bytes < in_img * p->N || (p->cin + 7) / 8 > p->in_units ||
         !p->dy_dev || !aligned16(p->dy_dev) || p->dy_bytes < dy_img * p->N || p->dy_unit_off < 0 ||
         p->dy_unit_off + (p->cout + 7) / 8 > p->dy_units) {
-        set_error("conv3x3_wgrad: input / gradient buffers missing, misaligned, too small or out of range");
+        set_error("%s: input / gradient buffers missing, misaligned, too small or out of range", who);
         return SR355_ERR_INVALID;
     }
-    if (!p->dw_dev || p->dw_bytes < (size_t)p->cout * p->cin * 9 * 4 || !p->workspace_dev ||
-        !aligned16(p->workspace_dev) ||
-        p->workspace_bytes < wgrad_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W)) {
-        set_error("conv3x3_wgrad: dw or workspace missing / too small (need %zu workspace bytes)",
-                  wgrad_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W));
+    const size_t need = wgrad_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W);
+    if (!p->dw_dev || p->dw_bytes < (size_t)p->cout * p->cin * 9 * 4 || !ws || !aligned16(ws) || ws_bytes < need) {
+        set_error("%s: dw or scratch missing / too small (this shape needs %zu scratch bytes, %zu available)", who,
+                  need, ws_bytes);
         return SR355_ERR_INVALID;
     }
+    return SR355_OK;
+}
+
+int sr355_conv3x3_wgrad(const sr355_wgrad_args *p, void *stream) {
+    const int rc = wgrad_checks("conv3x3_wgrad", p, p ? p->workspace_dev : nullptr, p ? p->workspace_bytes : 0);
+    if (rc) return rc;
     return launch_wgrad3x3(p->in_dev, p->in_units, p->upsample, p->dy_dev, p->dy_units, p->dy_unit_off, p->N, p->H,
                            p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev, p->db_dev,
                            (float *)p->workspace_dev, (hipStream_t)stream);
+}
+
+int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *p, void *stream) {
+    if (!p) {
+        set_error("conv3x3_wgrad_static: args is null");
+        return SR355_ERR_INVALID;
+    }
+    float *scratch = nullptr;
+    int rc = wgrad_static_scratch(&scratch);   // this device's copy of the library's scratch array
+    if (rc) return rc;
+    // the caller's workspace fields are ignored: the partial slabs go to the static array
+    if ((rc = wgrad_checks("conv3x3_wgrad_static", p, scratch, SR355_STATIC_SCRATCH_BYTES))) return rc;
+    return launch_wgrad3x3(p->in_dev, p->in_units, p->upsample, p->dy_dev, p->dy_units, p->dy_unit_off, p->N, p->H,
+                           p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev, p->db_dev, scratch,
+                           (hipStream_t)stream);
 }
 
 // ---- generator ----------------------------------------------------------------------------

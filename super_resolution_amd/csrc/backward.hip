@@ -15,6 +15,8 @@
 // * 2x2 sum pooling: the adjoint of the nearest x2 upsample fused in front of upconv1/upconv2.
 #include <string.h>
 
+#include <mutex>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -623,6 +625,36 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)9 * cout * cin + cout)), dim3(256), 0, stream, slabs,
                        dw, cout, cin, co_pad, G, scale, accumulate, a.bias_slabs, db);
     if (check_hip(hipGetLastError(), "wgrad reduce launch")) return SR355_ERR_HIP;
+    return SR355_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Scratch of the allocation-free weight gradient (sr355_conv3x3_wgrad_static): the per-workgroup partial slabs go
+// to this array of the code object instead of a caller workspace.  Every GPU the library runs on holds its own
+// copy until the process ends.  In host code the array's name is only a handle for the symbol lookup; the device
+// address of the current device's copy comes from hipGetSymbolAddress, once per device, and is what the kernels get.
+static __device__ __align__(256) unsigned char scratch[SR355_STATIC_SCRATCH_BYTES];
+
+int wgrad_static_scratch(float **out) {
+    static std::mutex mu;
+    static void *ptr_of[64] = {};
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+    if (dev < 0 || dev >= 64) {
+        set_error("conv3x3_wgrad_static: device ordinal %d outside [0, 64)", dev);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of[dev]) {
+        void *p = nullptr;
+        if (check_hip(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)")) return SR355_ERR_HIP;
+        if (!p) {
+            set_error("conv3x3_wgrad_static: the scratch symbol has no address on device %d", dev);
+            return SR355_ERR_HIP;
+        }
+        ptr_of[dev] = p;
+    }
+    *out = (float *)ptr_of[dev];
     return SR355_OK;
 }
 

@@ -103,6 +103,9 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream);
 
+// Device address, on the current device, of the library's static scratch array (SR355_STATIC_SCRATCH_BYTES).
+int wgrad_static_scratch(float **out);
+
 inline int unit_channels(int dtype) { return dtype == SR355_DTYPE_BF16 ? 8 : dtype == SR355_DTYPE_F32 ? 4 : -1; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int cin_units_for(int cin, int dtype) { return round_up((cin + unit_channels(dtype) - 1) / unit_channels(dtype), 2); }
