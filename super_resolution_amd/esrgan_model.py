@@ -35,16 +35,29 @@ def _conv(cin: int, cout: int) -> nn.Conv2d:
     return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1)
 
 
+def _is_replica(module: nn.Module) -> bool:
+    """True for a per-device copy made by ``nn.parallel.replicate`` (``nn.DataParallel`` builds them anew in
+    every forward)."""
+    return bool(module.__dict__.get("_is_replica", False))
+
+
 class _PackCache:
     """Packed copies of a module's conv parameters, rebuilt when any parameter changes.  One entry per (device,
     arithmetic): ``nn.DataParallel`` replicas share this object (``replicate`` copies a module's ``__dict__``
     shallowly) and call it from one thread per device, so an entry is read and replaced as a whole and a caller
-    only ever returns the pack it looked up or built itself."""
+    only ever returns the pack it looked up or built itself.
+
+    Only a module that owns its parameters may cache.  A replica's parameters are fresh broadcast outputs in every
+    forward: their version counters restart at 0 and the caching allocator hands out the same addresses again
+    iteration after iteration, so (version, address) of a replica says nothing about the values behind it.  A
+    replica (``cacheable=False``) therefore packs on every call and leaves the owner's entries alone."""
 
     def __init__(self) -> None:
         self.entries: Dict[Tuple, Tuple] = {}
 
-    def get(self, params: List[Tensor], dtype, builder):
+    def get(self, params: List[Tensor], dtype, builder, cacheable: bool = True):
+        if not cacheable:
+            return builder()
         slot = (dtype, params[0].device)
         key = (tuple(map(_VERSION_OF, params)), tuple(map(Tensor.data_ptr, params)))
         entry = self.entries.get(slot)
@@ -73,7 +86,7 @@ class ResidualDenseBlock(nn.Module):
     def _packed(self, dtype: int):
         params = [p for c in self._convs() for p in (c.weight, c.bias)]
         return self._cache.get(params, dtype, lambda: [ops.pack_weight(c.weight.detach(), c.bias.detach(), dtype)
-                                                        for c in self._convs()])
+                                                        for c in self._convs()], not _is_replica(self))
 
     def _run(self, buf: Tensor, trunk_in: Tensor, trunk_out: Tensor, nxt: Tensor, dtype: int,
              outer: Optional[Tensor] = None, outer_out: Optional[Tensor] = None) -> None:
@@ -227,7 +240,8 @@ class GeneratorRRDB(nn.Module):
         params = self.conv_parameters()
         cfg = self.cfg(inference)
         cache = self._cache_inf if cfg[6] == HR_F16 else self._cache
-        return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack_now(params[0::2], params[1::2], cfg))
+        return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack_now(params[0::2], params[1::2], cfg),
+                         not _is_replica(self))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:
         """Scratch memory of a no-grad forward, kept per device and grown on demand."""
@@ -246,7 +260,8 @@ class GeneratorRRDB(nn.Module):
     def packed_bwd_parameters(self) -> Tensor:
         weights = self.conv_parameters()[0::2]
         cfg = self.cfg()
-        return self._cache_bwd.get(weights, (cfg[5], cfg[6]), lambda: ops.generator_pack_bwd_now(weights, cfg))
+        return self._cache_bwd.get(weights, (cfg[5], cfg[6]), lambda: ops.generator_pack_bwd_now(weights, cfg),
+                                   not _is_replica(self))
 
     # -- forward --------------------------------------------------------------------------
     def forward(self, x: Tensor) -> Tensor:

@@ -147,3 +147,44 @@ def test_conv_parameter_list_follows_the_module_tree():
     assert [id(p) for p in net.conv_parameters()] == [id(p) for p in net.parameters()]
     assert [k for k, _ in net.named_parameters()] == [f"{n}.{s}" for n, m in net.named_modules()
                                                        if isinstance(m, nn.Conv2d) for s in ("weight", "bias")]
+
+
+def test_replicas_never_reuse_a_cached_pack(monkeypatch):
+    """An nn.DataParallel replica's parameters are fresh broadcast outputs every forward: version 0, recycled
+    addresses.  (version, address) therefore cannot key a cache for them: a replica must pack on every call, and the
+    owning module keeps caching."""
+    from super_resolution_amd import esrgan_model as M, ops
+    calls = []
+    monkeypatch.setattr(ops, "generator_pack_now", lambda w, b, cfg: calls.append("fwd") or object())
+    monkeypatch.setattr(ops, "generator_pack_bwd_now", lambda w, cfg: calls.append("bwd") or object())
+    monkeypatch.setattr(ops, "pack_weight", lambda w, b, dt: calls.append("rdb") or (None, None))
+    net = S.GeneratorRRDB(num_blocks=1)
+    # the owner caches: one pack for two calls, a new one after an in-place update
+    a, b = net.packed_parameters(), net.packed_parameters()
+    assert a is b and calls == ["fwd"]
+    with torch.no_grad():
+        net.conv_first.weight.add_(1.0)
+    assert net.packed_parameters() is not a and calls == ["fwd", "fwd"]
+    # a replica as nn.parallel.replicate builds it: same __dict__ (so the SAME cache objects), parameters as plain
+    # attributes at unchanged addresses with version counters at 0
+    del calls[:]
+    replica = net._replicate_for_data_parallel()
+    for name, mod in net.named_modules():
+        if name:
+            parent = replica if "." not in name else replica.get_submodule(name.rsplit(".", 1)[0])
+            rep = mod._replicate_for_data_parallel()
+            parent._modules[name.rsplit(".", 1)[-1]] = rep
+            for pname, p in mod._parameters.items():
+                setattr(rep, pname, p.detach())
+    assert M._is_replica(replica) and not M._is_replica(net)
+    p1, p2 = replica.packed_parameters(), replica.packed_parameters()
+    assert p1 is not p2 and calls == ["fwd", "fwd"]
+    replica.packed_bwd_parameters(), replica.packed_bwd_parameters()
+    assert calls == ["fwd", "fwd", "bwd", "bwd"]
+    rdb = replica.body[0].rdb1
+    rdb._packed(0), rdb._packed(0)
+    assert calls.count("rdb") == 10
+    # the replica left the owner's entry alone
+    n = len(calls)
+    net.packed_parameters()
+    assert len(calls) == n
