@@ -129,6 +129,35 @@ typedef struct sr355_conv_args {
 
 int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
 
+/* ---- a whole dense block in one launch (ResidualDenseBlock.forward, esrgan_model.py:18-24) ----
+ * For images at most 32 pixels wide (training patches), bf16, 64 block channels + 4 x 32 growth channels:
+ * conv1..conv4 (each followed by LeakyReLU, appended at units 8, 12, 16, 20 of the block buffer) and conv5 with
+ * the fused epilogue of sr355_conv3x3_fwd, bit-identical to the five sr355_conv3x3_fwd calls it replaces.  A
+ * workgroup owns two image rows and recomputes the halo rows of the growth outputs in LDS.
+ * The same entry point runs the five data-gradient convs of the block's backward pass on the transposed packs
+ * (sr355_pack_weight_transposed) and the mirrored gradient stack [dOut | dY4 | dY3 | dY2 | dY1]: zero biases,
+ * lrelu_slope 1, mask_dev = the block's saved forward buffer with mask_unit_off = {20, 16, 12, 8}. */
+typedef struct sr355_dense_block_args {
+    int N, H, W;                       /* W <= 32 */
+    void *buf_dev; size_t buf_bytes;   /* [N][H][24][W][16 B] bf16; units [0, 8) hold the block input            */
+    int store_growth;                  /* 1: steps 1..4 write their outputs to units [8, 24) of buf_dev (needed by
+                                          a backward pass); 0: they stay in LDS                                  */
+    const void *w_packed_dev[5]; size_t w_packed_bytes[5];   /* packed weights of conv1..conv5                   */
+    const float *bias_packed_dev[5];                          /* 32, 32, 32, 32, 64 floats                        */
+    float lrelu_slope;                 /* steps 1..4; 1.0f = none                                                */
+    const void *mask_dev; size_t mask_bytes;   /* optional sign gate of steps 1..4, as in sr355_conv_args        */
+    int mask_units, mask_unit_off[4];
+    float mask_slope;
+    /* step 5 (conv5, no activation): residuals and outputs as in sr355_conv_args, 64 channels */
+    const float *res1_dev; float res1_weight, res1_scale;
+    const float *res2_dev; float res2_weight, res2_scale;
+    size_t res_bytes;
+    const void *res_act_dev; size_t res_act_bytes; int res_act_units;
+    void *out_act_dev; size_t out_act_bytes; int out_units, out_unit_off;
+    float *out_f32_dev;
+} sr355_dense_block_args;
+int sr355_dense_block_fwd(const sr355_dense_block_args *args, void *stream);
+
 /* ---- backward pass of the convolution (autograd of esrgan_model.py:10-14 under
  *      loss.backward(), /root/reference/esrgan/train.py:161, :220) ---- */
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "sr355_abi_version", "sr355_last_error", "sr355_unit_channels",
     "sr355_nchw_to_blocked", "sr355_blocked_to_nchw",
     "sr355_packed_weight_bytes", "sr355_pack_weight",
-    "sr355_conv3x3_fwd",
+    "sr355_conv3x3_fwd", "sr355_dense_block_fwd",
     "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
     "sr355_conv3x3_wgrad_static",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
@@ -61,6 +61,26 @@ class ConvArgs(C.Structure):
         ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
         ("f16_in", C.c_int), ("f16_out", C.c_int),
         ("res_act_dev", C.c_void_p), ("res_act_bytes", C.c_size_t), ("res_act_units", C.c_int),
+    ]
+
+
+class DenseBlockArgs(C.Structure):
+    """Mirror of ``sr355_dense_block_args``."""
+    _fields_ = [
+        ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("buf_dev", C.c_void_p), ("buf_bytes", C.c_size_t), ("store_growth", C.c_int),
+        ("w_packed_dev", C.c_void_p * 5), ("w_packed_bytes", C.c_size_t * 5),
+        ("bias_packed_dev", C.c_void_p * 5),
+        ("lrelu_slope", C.c_float),
+        ("mask_dev", C.c_void_p), ("mask_bytes", C.c_size_t),
+        ("mask_units", C.c_int), ("mask_unit_off", C.c_int * 4), ("mask_slope", C.c_float),
+        ("res1_dev", C.c_void_p), ("res1_weight", C.c_float), ("res1_scale", C.c_float),
+        ("res2_dev", C.c_void_p), ("res2_weight", C.c_float), ("res2_scale", C.c_float),
+        ("res_bytes", C.c_size_t),
+        ("res_act_dev", C.c_void_p), ("res_act_bytes", C.c_size_t), ("res_act_units", C.c_int),
+        ("out_act_dev", C.c_void_p), ("out_act_bytes", C.c_size_t),
+        ("out_units", C.c_int), ("out_unit_off", C.c_int),
+        ("out_f32_dev", C.c_void_p),
     ]
 
 
@@ -122,6 +142,7 @@ def lib() -> C.CDLL:
     L.sr355_packed_weight_bytes.restype = sz
     L.sr355_pack_weight.argtypes = [vp, vp, i, i, i, i, vp, sz, vp, vp]
     L.sr355_conv3x3_fwd.argtypes = [C.POINTER(ConvArgs), vp]
+    L.sr355_dense_block_fwd.argtypes = [C.POINTER(DenseBlockArgs), vp]
     L.sr355_pack_weight_transposed.argtypes = [vp, i, i, i, i, i, f, vp, i, i, sz, vp]
     L.sr355_pool2x2_sum.argtypes = [vp, sz, i, i, i, i, i, vp, sz, i, i, f, vp, sz, vp, sz, i, i, vp]
     L.sr355_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]

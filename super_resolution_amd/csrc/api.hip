@@ -119,6 +119,15 @@ static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
     return w;
 }
 
+static ConvArgs conv_args_zero() {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.res1_w = a.res2_w = 1.f;
+    a.slope = 1.f;
+    a.mask_slope = 1.f;
+    return a;
+}
+
 }  // namespace sr355
 
 using namespace sr355;
@@ -331,6 +340,84 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     return launch_conv3x3(a, p->dtype, p->cin_units, p->weight_split != SR355_SPLIT_NONE, (hipStream_t)stream);
 }
 
+int sr355_dense_block_fwd(const sr355_dense_block_args *p, void *stream) {
+    if (!p) {
+        set_error("dense_block_fwd: args is null");
+        return SR355_ERR_INVALID;
+    }
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->W > 32) {
+        set_error("dense_block_fwd: bad shape N=%d H=%d W=%d (images at most 32 pixels wide)", p->N, p->H, p->W);
+        return p->W > 32 ? SR355_ERR_UNSUPPORTED : SR355_ERR_INVALID;
+    }
+    const size_t px = (size_t)p->N * p->H * p->W;
+    if (!p->buf_dev || !aligned16(p->buf_dev) || p->buf_bytes < px * 24 * 16) {
+        set_error("dense_block_fwd: block buffer missing, misaligned or smaller than %zu bytes", px * 24 * 16);
+        return SR355_ERR_INVALID;
+    }
+    for (int k = 0; k < 5; ++k) {
+        const size_t need = (size_t)(8 + 4 * k) * 9 * (k < 4 ? 32 : 64) * 16;
+        if (!p->w_packed_dev[k] || !aligned16(p->w_packed_dev[k]) || p->w_packed_bytes[k] < need ||
+            !p->bias_packed_dev[k] || !aligned16(p->bias_packed_dev[k])) {
+            set_error("dense_block_fwd: packed weights / bias of conv%d missing, misaligned or smaller than %zu bytes",
+                      k + 1, need);
+            return SR355_ERR_INVALID;
+        }
+    }
+    if (p->mask_dev) {
+        bool ok = aligned16(p->mask_dev) && p->mask_bytes >= px * p->mask_units * 16;
+        for (int k = 0; k < 4; ++k) ok = ok && p->mask_unit_off[k] >= 0 && p->mask_unit_off[k] + 4 <= p->mask_units;
+        if (!ok) {
+            set_error("dense_block_fwd: mask geometry invalid");
+            return SR355_ERR_INVALID;
+        }
+    }
+    if (!p->out_act_dev && !p->out_f32_dev) {
+        set_error("dense_block_fwd: no output requested");
+        return SR355_ERR_INVALID;
+    }
+    if ((p->res1_dev || p->res2_dev || p->out_f32_dev) &&
+        (p->res_bytes < px * 64 * 4 || !aligned16(p->res1_dev) || !aligned16(p->res2_dev) || !aligned16(p->out_f32_dev))) {
+        set_error("dense_block_fwd: residual / fp32 output tensors misaligned or smaller than %zu bytes", px * 64 * 4);
+        return SR355_ERR_INVALID;
+    }
+    if (p->res_act_dev && (p->res1_dev || !aligned16(p->res_act_dev) || p->res_act_units < 8 ||
+                           p->res_act_bytes < px * p->res_act_units * 16)) {
+        set_error("dense_block_fwd: res_act needs no res1, >= 8 units and %zu bytes", px * p->res_act_units * 16);
+        return SR355_ERR_INVALID;
+    }
+    if (p->out_act_dev && (p->out_unit_off < 0 || p->out_unit_off + 8 > p->out_units || !aligned16(p->out_act_dev) ||
+                           p->out_act_bytes < px * p->out_units * 16)) {
+        set_error("dense_block_fwd: activation output geometry invalid");
+        return SR355_ERR_INVALID;
+    }
+    DenseArgs d;
+    memset(&d, 0, sizeof(d));
+    d.buf = (const unsigned char *)p->buf_dev;
+    d.growth_out = p->store_growth ? (unsigned char *)p->buf_dev : nullptr;
+    for (int k = 0; k < 5; ++k) {
+        d.w[k] = (const unsigned char *)p->w_packed_dev[k];
+        d.bias[k] = p->bias_packed_dev[k];
+    }
+    d.mask = (const unsigned char *)p->mask_dev;
+    d.mask_units = p->mask_units;
+    for (int k = 0; k < 4; ++k) d.mask_off[k] = p->mask_unit_off[k];
+    d.mask_slope = p->mask_slope;
+    d.slope = p->lrelu_slope;
+    d.N = p->N, d.H = p->H, d.W = p->W, d.units = 24;
+    ConvArgs &a = d.tail;
+    a = conv_args_zero();
+    a.res1 = p->res1_dev, a.res1_w = p->res1_weight, a.res1_scale = p->res1_scale;
+    a.res2 = p->res2_dev, a.res2_w = p->res2_weight, a.res2_scale = p->res2_scale;
+    a.res_act = (const unsigned char *)p->res_act_dev;
+    a.res_act_units = p->res_act_units;
+    a.out_act = (unsigned char *)p->out_act_dev;
+    a.out_units = p->out_units, a.out_unit_off = p->out_unit_off;
+    a.out_f32 = p->out_f32_dev;
+    a.cout_real = a.cout_pad = 64;
+    a.f32_units = 16;
+    return launch_dense_block(d, (hipStream_t)stream);
+}
+
 // ---- backward primitives ------------------------------------------------------------------
 int sr355_pack_weight_transposed(const float *w, int cout, int cin, int ci_lo, int n_out, int dtype, float scale,
                                  void *wp, int packed_units, int unit_off, size_t wp_bytes, void *stream) {
@@ -489,15 +576,6 @@ struct FwdBufs {
     unsigned char *blk(int i) const { return blk_base + (size_t)(blk_count == 2 ? (i & 1) : i) * blk_stride; }
 };
 
-static ConvArgs conv_args_zero() {
-    ConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.res1_w = a.res2_w = 1.f;
-    a.slope = 1.f;
-    a.mask_slope = 1.f;
-    return a;
-}
-
 // Second stream of a device for the two-stream forward (created on first use, never destroyed) and the
 // fork/join events around it.
 constexpr int MAX_PARTS = 4;
@@ -539,6 +617,16 @@ static int batch_parts(int N, int H, int W) {
     const long long tiles_img = (long long)((W + 31) / 32) * ((H + 7) / 8);
     while (parts > 1 && (N / parts) * tiles_img < 256) --parts;
     return parts;
+}
+
+// A dense block as one launch (dense_block.hip) instead of five: for images at most 32 pixels wide whose two-row
+// bands do not overfill the chip many times over (the fused kernel recomputes halo rows: 2.15 x the MFMA work).
+// SR355_DENSE_FUSED=0 keeps the five-launch path; SR355_DENSE_FUSED_MAX overrides the band limit.
+static bool use_dense_fused(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    static const int knob = [] { const char *e = getenv("SR355_DENSE_FUSED"); return e ? atoi(e) : 1; }();
+    static const long long max_bands = [] { const char *e = getenv("SR355_DENSE_FUSED_MAX"); return e ? atoll(e) : 1024LL; }();
+    if (!knob || !dense_block_supported(cfg->num_features, cfg->growth_channels, cfg->dtype, W)) return false;
+    return (long long)N * ((H + 1) / 2) <= max_bands;
 }
 
 // Input: fp32 NCHW, or (in_u8) a uint8 HWC image batch read as byte / 255.  Output: fp32 NCHW unclamped, or (out_u8)
@@ -624,6 +712,46 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         return SR355_OK;
     };
 
+    // one dense block (:18-24) as a single launch; conv5's epilogue arguments as in `conv`
+    const bool fused = use_dense_fused(cfg, N, H, W);
+    auto dense = [&](unsigned char *cur, unsigned char *nxt, const float *res1, float s1, const float *res2, float s2,
+                     float *out_f32, bool res_from_act) -> int {
+        const size_t blk_img = (size_t)H * W * ws.blk_units * 16;
+        const size_t f32_img = (size_t)H * W * nf;   // floats
+        const ConvSpec *sp = &specs[ci];
+        ci += 5;
+        for (int p = 0; p < n_parts; ++p) {
+            const size_t n0 = (size_t)part_n0[p];
+            DenseArgs d;
+            memset(&d, 0, sizeof(d));
+            d.buf = cur + n0 * blk_img;
+            d.growth_out = fb.blk_count == 2 ? nullptr : cur + n0 * blk_img;   // kept only where a backward reads them
+            for (int k = 0; k < 5; ++k) {
+                d.w[k] = pk + sp[k].w_off;
+                d.bias[k] = (const float *)(pk + sp[k].b_off);
+            }
+            d.slope = 0.2f;
+            d.mask_slope = 1.f;
+            d.N = part_n[p], d.H = H, d.W = W, d.units = ws.blk_units;
+            ConvArgs &a = d.tail;
+            a = conv_args_zero();
+            a.out_act = nxt + n0 * blk_img;
+            a.out_units = ws.blk_units;
+            a.out_f32 = out_f32 ? out_f32 + n0 * f32_img : nullptr;
+            a.res_act = res_from_act ? cur + n0 * blk_img : nullptr;
+            a.res_act_units = ws.blk_units;
+            a.res1 = res1 ? res1 + n0 * f32_img : nullptr;
+            a.res2 = res2 ? res2 + n0 * f32_img : nullptr;
+            a.res1_scale = s1;
+            a.res2_scale = s2;
+            a.cout_real = a.cout_pad = nf;
+            a.f32_units = nf / 4;
+            const int rc_ = launch_dense_block(d, part_stream[p]);
+            if (rc_) return rc_;
+        }
+        return SR355_OK;
+    };
+
     int bi = 0;  // dense-block buffer index
     // conv_first (:56): x -> block buffer units [0, nf) and the fp32 copy F kept for the global skip.
     if ((rc = conv(fb.x0, ws.in_units, ws.in_units, H, W, 0, fb.blk(0), ws.blk_units, 0, 1.f, nullptr, 0.f, nullptr,
@@ -633,6 +761,16 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         const float *rrdb_in = (b == 0) ? F : R;  // fp32 input of this RRDB (:35)
         for (int r = 0; r < 3; ++r, ++bi) {
             unsigned char *cur = fb.blk(bi), *nxt = fb.blk(bi + 1);
+            if (fused) {
+                if (rrdb_only)
+                    rc = dense(cur, nxt, nullptr, 0.2f, r < 2 ? nullptr : rrdb_in, r < 2 ? 0.f : 0.2f, r < 2 ? nullptr : R,
+                               true);
+                else
+                    rc = dense(cur, nxt, (r == 0) ? rrdb_in : T, 0.2f, r < 2 ? nullptr : rrdb_in, r < 2 ? 0.f : 0.2f,
+                               r < 2 ? T : R, false);
+                if (rc) return rc;
+                continue;
+            }
             for (int k = 0; k < 4; ++k) {  // growth convs (:19-22): read [0, nf+k*gc), append gc channels
                 if ((rc = conv(cur, ws.blk_units, (nf + k * gc) / cpu, H, W, 0, cur, ws.blk_units,
                                (nf + k * gc) / cpu, 0.2f, nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
@@ -952,7 +1090,7 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
 
 // Backward workspace.
 struct BwdWs {
-    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, dfea, slabs, total;
+    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, dfea, slabs, total;
 };
 
 static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
@@ -977,6 +1115,7 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     b.gR = take(P * c.num_features * 4);
     b.GB0 = take(P * ws.blk_units * 16);
     b.GB1 = take(P * ws.blk_units * 16);
+    b.GB2 = take(P * ws.blk_units * 16);   // third gradient stack of the one-launch dense-block backward
     b.dfea = take(P * ws.nf_units * 16);
     size_t slab = 0;
     const int nf = c.num_features, gc = c.growth_channels;
@@ -1145,7 +1284,13 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                  i_last = i_trunk + 4;
     const int ou = cin_units_for(cfg->out_channels, dt);
     int rc = SR355_OK;
-    unsigned char *GB[2] = {wb + bw.GB0, wb + bw.GB1};
+    // Gradient stacks, rotated once per dense block.  Five launches per block: two stacks (the final step of a block
+    // writes the next stack's units [0, nf) only after the weight gradients that read that stack are done).  One
+    // launch per block: three, because the single launch also fills its own stack's growth units, which must not
+    // be the stack the previous block's weight gradients are still reading.
+    const bool fused = use_dense_fused(cfg, N, H, W);
+    const int n_gb = fused ? 3 : 2;
+    unsigned char *GB[3] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2};
     if (phase_begin == 0) {
     // grad_out -> blocked bf16
     if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
@@ -1187,12 +1332,63 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     for (int b = nb - 1; b >= 0; --b) {
         const int phase = nb - b;
         if (phase < phase_begin || phase >= phase_end) continue;
-        int cur = (3 * (nb - 1 - b)) & 1;
+        int cur = (3 * (nb - 1 - b)) % n_gb;
         for (int r = 2; r >= 0; --r) {
             const int i = 3 * b + r;
             const unsigned char *A = sb + sv.blk + (size_t)i * sv.blk_stride;   // forward activations of this block
             const size_t c1 = 1 + (size_t)i * 5;                                 // conv1 of this block in `specs`
             const float s5 = (r == 2) ? 0.04f : 0.2f;
+            if (fused) {
+                // the block's five data gradients in one launch, then its five weight gradients on the side stream
+                const int nxt = (cur + 1) % n_gb;
+                const int par = blocks_done & 1;
+                // GB[nxt] was the stack of the block two before this one: its weight gradients must be done
+                if (blocks_done > 1 && side_await(par)) return SR355_ERR_HIP;
+                DenseArgs d;
+                memset(&d, 0, sizeof(d));
+                d.buf = GB[cur];
+                d.growth_out = GB[cur];
+                for (int k = 0; k < 4; ++k) {   // step k + 1 produces dY(4 - k)
+                    d.w[k] = pk + bp.rdb[(size_t)i * 5 + (4 - k)];
+                    d.bias[k] = zero_bias;
+                    d.mask_off[k] = (nf + (3 - k) * gc) / 8;
+                }
+                d.w[4] = pk + bp.rdb[(size_t)i * 5];
+                d.bias[4] = zero_bias;
+                d.mask = A;
+                d.mask_units = bu;
+                d.mask_slope = 0.2f;
+                d.slope = 1.f;
+                d.N = N, d.H = H, d.W = W, d.units = bu;
+                ConvArgs &a = d.tail;
+                a = conv_args_zero();
+                a.res1_scale = a.res2_scale = 1.f;
+                if (r == 2) {          // dX3 = 0.2 gR + conv
+                    a.res1 = gR, a.res1_w = 0.2f, a.out_f32 = gT;
+                } else if (r == 1) {   // dX2 = dX3 + conv
+                    a.res1 = gT, a.res1_w = 1.f, a.out_f32 = gT;
+                } else {               // gradient of the RRDB input = gR + dX2 + conv
+                    a.res1 = gT, a.res1_w = 1.f, a.res2 = gR, a.res2_w = 1.f, a.out_f32 = gR;
+                }
+                a.out_act = GB[nxt];
+                a.out_units = bu;
+                a.cout_real = a.cout_pad = nf;
+                a.f32_units = nf / 4;
+                if ((rc = launch_dense_block(d, stream))) return rc;
+                float *dw[5], *db[5];
+                for (int k = 0; k < 5; ++k) {
+                    dw[k] = grads + goff[c1 + k];
+                    db[k] = dw[k] + (size_t)specs[c1 + k].cout * specs[c1 + k].cin * 9;
+                }
+                if (ss && (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
+                           check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))
+                    return SR355_ERR_HIP;
+                if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
+                if (side_mark(par)) return SR355_ERR_HIP;
+                ++blocks_done;
+                cur = nxt;
+                continue;
+            }
             // the four growth convs' data gradients fill the stack; then its five weight gradients go to the side
             // stream behind one hand-off (conv5: dY5 = s5 * the gradient held in GB[cur] units [0, nf))
             for (int j = 4; j >= 1; --j) {
@@ -1213,7 +1409,7 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                     return SR355_ERR_HIP;
                 if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
             }
-            const int nxt = cur ^ 1;
+            const int nxt = (cur + 1) % n_gb;
             // the next write goes to GB[nxt] units [0, nf): the conv5 weight gradient of the dense block before
             // this one reads them, and this block's own stack is rewritten one block later
             const int par = blocks_done & 1;

@@ -45,6 +45,25 @@ struct ConvArgs {
     unsigned long long *trace;   // timing experiments only: 16 wall-clock stamps per workgroup, normally null
 };
 
+// Arguments of one fused dense-block launch (dense_block.hip): five convs over one 24-unit block buffer.
+struct DenseArgs {
+    const unsigned char *buf;      // [N][H][24][W][16 B] bf16: units [0, 8) hold the block input
+    unsigned char *growth_out;     // where steps 1..4 store their 32 channels each (units 8..23 of a buffer of the
+                                   // same geometry, normally `buf` itself), or null: kept in LDS only
+    const unsigned char *w[5];     // packed weights of conv1..conv5 ([cin_units][9][cout_pad][16 B])
+    const float *bias[5];          // 32, 32, 32, 32, 64 floats
+    const unsigned char *mask;     // data-gradient use: saved activations whose sign gates steps 1..4, or null
+    int mask_units, mask_off[4];   // units per pixel of `mask`, unit offset of the gate of step k + 1
+    float mask_slope;
+    float slope;                   // LeakyReLU slope of steps 1..4 (1.0f = identity)
+    int N, H, W, units;
+    int n_bands;                   // set by the launcher
+    int debug;                     // timing experiments only (builds with SR355_TRACE): bit 0 = no weight traffic,
+                                   // bit 2 = no L2 prefetch
+    unsigned long long *trace;     // timing experiments only: 8 shader-clock + 8 wall-clock stamps per workgroup
+    ConvArgs tail;                 // conv5's epilogue: residuals, carriers, outputs (cout 64); N/H/W set by the launcher
+};
+
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 
@@ -57,6 +76,10 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
 // Ring kernel with a branch-free, MFMA-interleaved stage body; n_stages, n_real_stages and debug must be set.
 int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream);
 int launch_conv3x3_fine_small(const ConvArgs &a, hipStream_t stream);
+
+// Fused dense block for images at most 32 pixels wide (bf16, 64 features, 32 growth channels).
+bool dense_block_supported(int nf, int gc, int dtype, int W);
+int launch_dense_block(const DenseArgs &a, hipStream_t stream);
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,
                            int dst_units, int split, hipStream_t stream);

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, GeneratorCfg, WgradArgs, check
+from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, DenseBlockArgs, GeneratorCfg, WgradArgs, check
 
 _TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
 _CODE = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}
@@ -198,6 +198,51 @@ def conv3x3_fwd(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: T
 def _(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res1, res1_scale, res2, res2_scale,
       out_act, out_unit_off, out_f32, out_nchw, weight_split=0, mask=None, mask_unit_off=0, mask_slope=1.0,
       res1_weight=1.0, res2_weight=1.0):
+    return None
+
+
+DENSE_BLOCK_MAX_WIDTH = 32
+
+
+@torch.library.custom_op("sr355::dense_block_fwd", mutates_args=("buf", "out_act", "out_f32"))
+def dense_block_fwd(buf: Tensor, w_packed: List[Tensor], bias_packed: List[Tensor], lrelu_slope: float,
+                    store_growth: bool, res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor],
+                    res2_scale: float, out_act: Optional[Tensor], out_f32: Optional[Tensor],
+                    mask: Optional[Tensor] = None, mask_unit_off: Optional[List[int]] = None, mask_slope: float = 1.0,
+                    res1_weight: float = 1.0, res2_weight: float = 1.0, res_act: Optional[Tensor] = None) -> None:
+    """A whole dense block (conv1..conv4 + LeakyReLU appended to ``buf``, conv5 with the fused skip epilogue) in one
+    launch, for blocked bf16 buffers ``[N, H, 24, W <= 32, 8]``; bit-identical to five ``conv3x3_fwd`` calls."""
+    _need_cuda(buf, res1, res2, out_act, out_f32, mask, res_act, *w_packed, *bias_packed)
+    if buf.dtype != torch.bfloat16 or buf.dim() != 5 or buf.shape[2] != 24 or len(w_packed) != 5 or len(bias_packed) != 5:
+        raise RuntimeError("dense_block_fwd: expected a blocked bf16 buffer [N, H, 24, W, 8] and five packed convs")
+    a = DenseBlockArgs()
+    a.N, a.H, a.W = int(buf.shape[0]), int(buf.shape[1]), int(buf.shape[3])
+    a.buf_dev, a.buf_bytes, a.store_growth = buf.data_ptr(), _nbytes(buf), int(bool(store_growth))
+    for k in range(5):
+        a.w_packed_dev[k], a.w_packed_bytes[k] = w_packed[k].data_ptr(), _nbytes(w_packed[k])
+        a.bias_packed_dev[k] = bias_packed[k].data_ptr()
+    a.lrelu_slope = float(lrelu_slope)
+    if mask is not None:
+        a.mask_dev, a.mask_bytes, a.mask_units = mask.data_ptr(), _nbytes(mask), int(mask.shape[2])
+        for k in range(4):
+            a.mask_unit_off[k] = int(mask_unit_off[k])
+    a.mask_slope = float(mask_slope)
+    a.res1_dev, a.res1_weight, a.res1_scale = _ptr(res1), float(res1_weight), float(res1_scale)
+    a.res2_dev, a.res2_weight, a.res2_scale = _ptr(res2), float(res2_weight), float(res2_scale)
+    sizes = [_nbytes(t) for t in (res1, res2, out_f32) if t is not None]
+    a.res_bytes = min(sizes) if sizes else 0
+    if res_act is not None:
+        a.res_act_dev, a.res_act_bytes, a.res_act_units = res_act.data_ptr(), _nbytes(res_act), int(res_act.shape[2])
+    a.out_act_dev, a.out_act_bytes = _ptr(out_act), _nbytes(out_act)
+    a.out_units = int(out_act.shape[2]) if out_act is not None else 0
+    a.out_f32_dev = _ptr(out_f32)
+    with _on(buf.device):
+        check(_lib.lib().sr355_dense_block_fwd(C.byref(a), _stream()), "sr355_dense_block_fwd")
+
+
+@dense_block_fwd.register_fake
+def _(buf, w_packed, bias_packed, lrelu_slope, store_growth, res1, res1_scale, res2, res2_scale, out_act, out_f32,
+      mask=None, mask_unit_off=None, mask_slope=1.0, res1_weight=1.0, res2_weight=1.0, res_act=None):
     return None
 
 

@@ -2,7 +2,7 @@
 """Host profile of the pixel training iteration with the backward on the calling thread (so cProfile sees it)."""
 import cProfile, os, pstats, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import super_resolution_amd as S
 
 dev = torch.device("cuda:0")

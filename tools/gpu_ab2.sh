@@ -5,7 +5,7 @@ i=0
 for v in "$@"; do
   i=$((i+1))
   ( IFS=','; for kv in $v; do export "$kv"; done
-    timeout -s KILL 90 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ab/v$i -- python3 tools_prof_conv.py 5 > gpurun_out/ab/v$i.log 2>&1 ) || { echo "variant $v failed"; tail -3 gpurun_out/ab/v$i.log; exit 1; }
+    timeout -s KILL 90 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ab/v$i -- python3 tools/prof_conv.py 5 > gpurun_out/ab/v$i.log 2>&1 ) || { echo "variant $v failed"; tail -3 gpurun_out/ab/v$i.log; exit 1; }
   python3 - "$v" gpurun_out/ab/v$i <<'PY'
 import csv,glob,sys,collections
 rows=list(csv.DictReader(open(glob.glob(sys.argv[2]+'/vm/*kernel_trace.csv')[0])))

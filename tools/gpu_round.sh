@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session: parity tests, bench line, rocprofv3 kernel summary.  Usage: tools_gpu_round.sh TAG
+# One GPU-box session: parity tests, bench line, rocprofv3 kernel summary.  Usage: tools/gpu_round.sh TAG
 TAG=${1:-r}
 mkdir -p gpurun_out
 timeout -k 10 700 python -u -m pytest tests -m gpu -q -s --timeout 300 --timeout-method thread > gpurun_out/tests_$TAG.log 2>&1

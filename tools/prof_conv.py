@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch each distinct body-conv configuration of BASELINE config 2 a few times (for rocprofv3 passes).
 
-    python3 tools_prof_conv.py [reps]            # env SR355_RING=0/1 selects the kernel variant
+    python3 tools/prof_conv.py [reps]            # env SR355_RING=0/1 selects the kernel variant
 """
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import super_resolution_amd as S
 from super_resolution_amd import _lib, ops
 

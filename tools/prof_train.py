@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The generator's pixel-loss training step a few times (for rocprofv3 passes and wall-clock timing).
 
-    python3 tools_prof_train.py [steps] [batch] [lr_size]
+    python3 tools/prof_train.py [steps] [batch] [lr_size]
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import super_resolution_amd as S
 
 

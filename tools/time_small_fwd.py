@@ -2,7 +2,7 @@
 """GPU time of the generator forward at the training shape (16 x 3 x 32 x 32), no-grad, back to back."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import super_resolution_amd as S
 
 dev = torch.device("cuda:0")
