@@ -155,8 +155,9 @@ struct WgradArgs {
     // batched launch (blockIdx.z = conv of a dense block sharing `in` and `dy`): per-conv channel chunks,
     // workgroups per chunk, position of its gradient in dy and of its slabs; n_batch = 0: single conv
     int n_batch;
-    int z_chunks[4], z_groups[4], z_dy_unit_off[4];
-    long long z_slab_off[4], z_bias_off[4];   // in floats from `slabs`; bias < 0: none
+    int z_chunks[6], z_groups[6], z_dy_unit_off[6];
+    int z_co_off[6], z_co_stride[6];          // a job's 32 outputs sit at rows [co_off, co_off + 32) of slabs co_stride wide
+    long long z_slab_off[6], z_bias_off[6];   // in floats from `slabs`; bias < 0: none
 };
 
 namespace {
@@ -175,7 +176,8 @@ struct WGeo {
     static constexpr int KMAX = (JTOT + 2) / 3;
     static constexpr int IN_OFF = DY_I * 1024;
     static constexpr int STAGE_BYTES = JTOT * 1024;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int N_STAGES = MB == 1 ? 3 : 2;       // tiles in LDS: one being multiplied, the others in flight
+    static constexpr int LDS_BYTES = N_STAGES * STAGE_BYTES;
 };
 }  // namespace
 
@@ -206,6 +208,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     } a = {a0.in, a0.dy, a0.slabs, a0.bias_slabs, a0.N, a0.H, a0.W, a0.in_units, a0.ups, a0.dy_units, a0.dy_unit_off,
            a0.tiles_x, a0.tiles_y};
     int nwg = gridDim.x;
+    int co_off = 0, co_stride = G::CO;
     if (a0.n_batch > 0) {
         const int z = blockIdx.z;
         nwg = a0.z_groups[z];
@@ -213,6 +216,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         a.dy_unit_off = a0.z_dy_unit_off[z];
         a.bias_slabs = a0.z_bias_off[z] >= 0 ? a0.slabs + a0.z_bias_off[z] : nullptr;
         a.slabs = a0.slabs + a0.z_slab_off[z];
+        co_off = a0.z_co_off[z];
+        co_stride = a0.z_co_stride[z];
     }
     const int H = a.H, W = a.W;
     const int Win = W >> a.ups;
@@ -298,18 +303,32 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     const int dy_lane = (unit_in_block * WPX + 8 * k_half + q) * 16 + byte_in_unit;
     const int in_lane = G::IN_OFF + (unit_in_block * WIPX + wave * 34 + 8 * k_half + q) * 16 + byte_in_unit;
 
-    int t = blockIdx.x;
-    int slot = 0;
-    if (t < n_tiles) {
-        SR355_WG_SETUP(t);
+    // Tiles blockIdx.x, + nwg, ...: a ring of N_STAGES slots, AHEAD tiles in flight behind the one being multiplied
+    // (a tile is 24 MFMAs per wave against one memory latency, so the depth of the ring is what sets the pace).
+    // With 32 outputs every wave issues the same number of DMA instructions per tile (JTOT is a multiple of the 3
+    // waves), which is what the counted wait of the three-slot ring relies on.
+    static_assert(MB != 1 || G::JTOT % 3 == 0, "counted waits need equal DMA counts per wave");
+    const int n_my = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
+    if (n_my > 0) {
+        SR355_WG_SETUP((int)blockIdx.x);
         SR355_WG_ISSUE(0);
     }
-    for (; t < n_tiles; t += nwg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int AHEAD = G::N_STAGES - 1;
+    if (AHEAD > 1 && n_my > 1) {
+        SR355_WG_SETUP((int)blockIdx.x + nwg);
+        SR355_WG_ISSUE(1);
+    }
+    int slot = 0;
+    for (int it = 0; it < n_my; ++it) {
+        if (AHEAD == 2 && it + 1 < n_my)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::KMAX) : "memory");   // the next tile may still be in flight
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + nwg < n_tiles) {
-            SR355_WG_SETUP(t + nwg);
-            SR355_WG_ISSUE(slot ^ 1);
+        if (it + AHEAD < n_my) {
+            const int slot2 = slot + AHEAD >= G::N_STAGES ? slot + AHEAD - G::N_STAGES : slot + AHEAD;
+            SR355_WG_SETUP((int)blockIdx.x + (it + AHEAD) * nwg);
+            SR355_WG_ISSUE(slot2);
         }
         const unsigned char *buf = smem + slot * G::STAGE_BYTES;
 #pragma unroll
@@ -337,12 +356,12 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
                 }
             }
         }
-        slot ^= 1;
+        slot = slot + 1 == G::N_STAGES ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // slab [tap][co][ci32]; accumulator element: row (co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col (ci) = lane&31
-    float *slab = a.slabs + ((size_t)chunk * nwg + blockIdx.x) * 9 * G::CO * 32;
+    float *slab = a.slabs + ((size_t)chunk * nwg + blockIdx.x) * 9 * co_stride * 32 + (size_t)co_off * 32;
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
@@ -351,14 +370,14 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rowc = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                slab[((wave * 3 + kx) * G::CO + rowc) * 32 + col] = acc[kx][mb][e];
+                slab[((wave * 3 + kx) * co_stride + rowc) * 32 + col] = acc[kx][mb][e];
             }
     if (do_bias && col == 0) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                a.bias_slabs[(size_t)blockIdx.x * G::CO + mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = accb[mb][e];
+                a.bias_slabs[(size_t)blockIdx.x * co_stride + co_off + mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = accb[mb][e];
     }
 }
 
@@ -484,7 +503,7 @@ void wgrad_geometry(int cin, int N, int H, int W, int *chunks, int *G) {
     const int cin_units = (cin + 7) / 8;
     *chunks = (cin_units + 3) / 4;
     const long long tiles = (long long)N * ((H + WTH - 1) / WTH) * ((W + 31) / 32);
-    long long g = tiles / 4;
+    long long g = tiles / 8;   // eight tiles per workgroup: the partial slabs, not the MFMAs, are what a launch moves
     const long long cap = 768 / *chunks;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -551,6 +570,7 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
         rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[k], db[k], cout, cin, co_pad, G, k < 4 ? 1.f : s5};
         if (k < 4) {
             a.z_chunks[k] = chunks, a.z_groups[k] = G, a.z_dy_unit_off[k] = dy_off;
+            a.z_co_off[k] = 0, a.z_co_stride[k] = co_pad;
             a.z_slab_off[k] = (long long)off, a.z_bias_off[k] = (long long)bias_off;
             if (chunks > max_chunks) max_chunks = chunks;
             if (G > max_g) max_g = G;
@@ -558,25 +578,23 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
         off += ((wgrad_workspace_bytes(cout, cin, N, H, W) + 255) & ~(size_t)255) / sizeof(float);
     }
     int rc;
-    if ((rc = wgrad_set_attr(0)) || (rc = wgrad_set_attr(1))) return rc;
-    a.n_batch = 4;
-    hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
-    if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
-    // conv5 on its own (64 output channels take the two-block instantiation)
-    WgradArgs a5 = a;
-    a5.n_batch = 0;
-    a5.dy_unit_off = 0;
-    a5.slabs = const_cast<float *>(rt.j[4].slabs);
-    a5.bias_slabs = const_cast<float *>(rt.j[4].bias_slabs);
-    {
+    if ((rc = wgrad_set_attr(0))) return rc;
+    // conv5 joins the launch as two more jobs of 32 outputs each, written side by side into its 64-wide slabs
+    const int n5 = cout_pad_for(nf) / 32;
+    for (int half = 0; half < n5; ++half) {
+        const int z = 4 + half;
         int chunks, G;
         wgrad_geometry(nf + 4 * gc, N, H, W, &chunks, &G);
-        if (cout_pad_for(nf) == 64)
-            hipLaunchKernelGGL(wgrad3x3_kernel_mb2, dim3(G, chunks, 1), dim3(192), WGeo<2>::LDS_BYTES, stream, a5);
-        else
-            hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(G, chunks, 1), dim3(192), WGeo<1>::LDS_BYTES, stream, a5);
-        if (check_hip(hipGetLastError(), "wgrad3x3 conv5 launch")) return SR355_ERR_HIP;
+        a.z_chunks[z] = chunks, a.z_groups[z] = G, a.z_dy_unit_off[z] = half * 4;
+        a.z_co_off[z] = half * 32, a.z_co_stride[z] = cout_pad_for(nf);
+        a.z_slab_off[z] = (long long)(rt.j[4].slabs - slabs);
+        a.z_bias_off[z] = (long long)(rt.j[4].bias_slabs - slabs);
+        if (chunks > max_chunks) max_chunks = chunks;
+        if (G > max_g) max_g = G;
     }
+    a.n_batch = 4 + n5;
+    hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4 + n5), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
+    if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
     const size_t biggest = (size_t)9 * nf * (nf + 4 * gc) + nf;
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(grid_for(biggest), 5), dim3(256), 0, stream, rt, 0);
     return check_hip(hipGetLastError(), "wgrad reduce batch launch");

@@ -46,6 +46,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int DB_OOB = 0x7fffff00;   // byte offset beyond any descriptor range: the DMA writes zeros
@@ -86,7 +87,7 @@ __device__ __forceinline__ void wave_rows(int rows, int wv, int &i0, int &nb) {
 // LDS reads of data that plain stores or long-landed DMA wrote, issued through inline asm: the compiler orders every
 // LDS read it can see behind ALL LDS-DMA still in flight (s_waitcnt vmcnt(0)), which would drain the weight ring at
 // each use.  The callers guarantee by their own waits and barriers that the bytes read are in place.
-__device__ __forceinline__ void db_lds_read16x4(const unsigned char *p, int stride, uint4 (&v)[4]) {
+__device__ __forceinline__ void db_lds_read16x4(const unsigned char *p, int stride, v4u (&v)[4]) {
     const unsigned b = (unsigned)(size_t)p;
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
                  "s_waitcnt lgkmcnt(0)"
@@ -143,10 +144,13 @@ __device__ __forceinline__ void db_issue_chunk(DbRing &g, const DenseArgs &a, un
 
 // MFMA = 0x008, VMEM read = 0x020, DS read = 0x100: one MFMA, then its share of the LDS reads and of the DMA
 // instructions issued in its shadow
-#define DB_INTERLEAVE(N_MFMA, N_DS, N_VMEM, SYNC)                                                             \
+#define DB_INTERLEAVE(N_MFMA, N_DS, N_VMEM, SYNC) DB_INTERLEAVE_V(N_MFMA, N_DS, N_VMEM, 0, SYNC)
+// ... and N_VALU vector instructions per MFMA (a deferred epilogue's arithmetic; VALU = 0x002, DS write = 0x200)
+#define DB_INTERLEAVE_V(N_MFMA, N_DS, N_VMEM, N_VALU, SYNC)                                                   \
     {                                                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < (N_MFMA); ++i_) {                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, SYNC);                                             \
+            if ((N_VALU) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (N_VALU), SYNC);                    \
             _Pragma("unroll") for (int j_ = 0; j_ < ((N_DS) + (N_MFMA)-1) / (N_MFMA); ++j_)                   \
                 if (i_ * (((N_DS) + (N_MFMA)-1) / (N_MFMA)) + j_ < (N_DS))                                    \
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, SYNC);                                     \
@@ -154,23 +158,71 @@ __device__ __forceinline__ void db_issue_chunk(DbRing &g, const DenseArgs &a, un
         }                                                                                                     \
     }
 
+// What the device functions below share.
+struct DbCtx {
+    const DenseArgs &a;
+    unsigned char *smem;
+    int tid, wave, r, h, n, y0, img_bytes;
+    int pvoff[3];
+    float slope, mslope;   // copies of the launch arguments the epilogues use (not re-read from the argument segment)
+    int H, W;
+};
+
+// Epilogue of one row of growth step J: bias, LeakyReLU (as max(v, slope v): the launcher admits slopes in [0, 1]
+// only), sign gate, zero outside the image, bf16 into the step's LDS array.  `row` is the row's index in the array.
+template <int J, int Q0, int Q1, bool GATED>
+__device__ __forceinline__ void db_growth_quads(const f32x16 &acc, const v2u (&mraw)[4], const v4u (&braw)[4], int row,
+                                                const DbCtx &c) {
+    const float slope = c.slope, mslope = c.mslope;
+    const int y = c.y0 - (5 - J) + row;
+    const unsigned keep = (y >= 0 && y < c.H && c.r < c.W) ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        const float4 bv = __builtin_bit_cast(float4, braw[q]);
+        const float v[4] = {acc[4 * q + 0] + bv.x, acc[4 * q + 1] + bv.y, acc[4 * q + 2] + bv.z, acc[4 * q + 3] + bv.w};
+        const bf16x4 mv = __builtin_bit_cast(bf16x4, mraw[q]);
+        bf16x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = __builtin_fmaxf(v[j], v[j] * slope);
+            if constexpr (GATED) t = (float)mv[j] > 0.f ? t : t * mslope;
+            pk[j] = (__bf16)t;
+        }
+        v2u o = __builtin_bit_cast(v2u, pk);
+        o.x &= keep, o.y &= keep;
+        *reinterpret_cast<v2u *>(c.smem + base_of(J) + ((q * rows_of(J) + row) * DB_P + c.r + 1) * 16 + c.h * 8) = o;
+    }
+}
+
 // One conv of the block for this wave's NB consecutive output rows [i0, i0 + NB) and one block of 32 outputs.
 //   J : step 1..5; it reads 4 two-unit stages of the input array (K = 0) and 2 of each growth array K = 1..J-1
 //   CO: outputs per row of a weight chunk.  32: a chunk is a whole stage [2 units][9 taps][32][16 B].  64 (conv5):
 //       a chunk is one unit [9 taps][64][16 B], a stage reads two chunks and this wave the outputs [32 mb, 32 mb + 32)
+//   JP, NBP: the previous growth step and the rows of it this wave holds in `pacc` (NBP = 0: none).  That step's
+//       epilogue runs here, one row per stage under the MFMAs of stages 0..NBP-1, instead of between the two convs
+//       where nothing would cover it: stages 0..3 of a step read only the input array and older growth arrays.  From
+//       the barrier of stage 3 on every wave's rows of growth array JP are in LDS; the band's own rows are copied
+//       to the block buffer in that stage.
 // Per stage: wait for its chunk(s), barrier (the chunk has landed for every wave; every wave is done with the
 // previous stage's slot), refill the freed slot(s), then three tap columns.  The loop is software-pipelined so that
 // the wave alone keeps its SIMD's matrix pipe fed: the fragments of column kx + 1 are read from LDS under the MFMAs of
 // column kx, the last column of a stage is multiplied after the next stage's barrier (under the latency of that
 // stage's first weight fragments), and the first activation fragments of the next stage (resident data, independent
 // of the ring) are read before its barrier.  Accumulation order per output: stage, tap column, tap row.
-template <int J, int NB, int CO>
-__device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], DbRing &ring, int &c_slot, const DenseArgs &a,
-                                        unsigned char *smem, int wave, int r, int h, const int (&pvoff)[3], int i0,
-                                        int mb) {
+template <int J, int NB, int CO, int JP, int NBP, bool GATED>
+__device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], const f32x16 (&pacc)[NBP > 0 ? NBP : 1],
+                                        const v2u (&praw)[3][4], int i0p, DbRing &ring, int &c_slot, const DbCtx &c,
+                                        int i0, int mb) {
     constexpr int S = 2 + 2 * J;
     constexpr int NX = NB + 2;
+    constexpr int COPY_STAGE = 3;
+    static_assert(NBP == 0 || (NBP <= COPY_STAGE && S > COPY_STAGE + 1), "the deferred epilogue must finish before its array is read");
+    const DenseArgs &a = c.a;
+    unsigned char *smem = c.smem;
+    const int r = c.r, h = c.h;
     bf16x8 w0[3], x0[NX], w1[3], x1[NX], w2[3], x2[NX];
+    v4u braw[4] = {};   // the previous step's 16 bias values of this lane: channels q*8 + h*4 + j
+    if constexpr (NBP > 0) db_lds_read16x4(smem + DB_BIAS_OFF + (JP - 1) * 256 + h * 16, 32, braw);
     const int lane16 = r * 16;
     // activation fragments of stage t: unit 2 ss + h of source K, rows i0 + (J - K) - 1 + rho
     auto stage_ptr = [&](int t) -> const unsigned char * {
@@ -192,12 +244,12 @@ __device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], DbRing &ring, int &c_
     }
     const unsigned char *pa = stage_ptr(0);
     DB_LOAD_X(x0, 0);
+#pragma unroll
     for (int t = 0; t < S; ++t) {
         // every LDS read of the previous stage's weight slot has returned before the barrier lets it be refilled
-        // (the NX youngest reads are the activation prefetch above)
+        // (the NX youngest LDS operations are the activation prefetch above)
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NX) : "memory");
         // refills of this stage: one chunk (two per conv5 stage after the first), issued further down under MFMAs
-        int n_issue = 1;
         if constexpr (CO == 32) {
             // three younger chunks may be in flight (three DMA instructions each per wave)
             asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -207,7 +259,6 @@ __device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], DbRing &ring, int &c_
         } else {
             // steady state: one younger chunk in flight, two slots free after the barrier
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            n_issue = 2;
         }
         __builtin_amdgcn_s_barrier();
         const unsigned char *pw;
@@ -223,34 +274,52 @@ __device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], DbRing &ring, int &c_
         DB_LOAD_W(w0, 0);
         if (t > 0) { DB_MMA(w2, x2); }
         __builtin_amdgcn_sched_barrier(0);
-        // column 0: its MFMAs, the reads of column 1 and the refill of the freed slot, one of each at a time (an
-        // LDS-DMA instruction costs its wave 60-180 issue cycles: in the shadow of an MFMA, not in front of it)
-        db_issue_chunk(ring, a, smem, wave, pvoff);
+        // column 0: its MFMAs, the reads of column 1, the refill of the freed slot and one row of the previous
+        // step's epilogue, interleaved (an LDS-DMA instruction costs its wave 60-180 issue cycles and the epilogue
+        // some sixty vector instructions: in the shadow of the MFMAs, not in front of them)
+        db_issue_chunk(ring, a, smem, c.wave, c.pvoff);
         DB_LOAD_W(w1, 1);
         DB_LOAD_X(x1, 1);
         DB_MMA(w0, x0);
-        DB_INTERLEAVE(3 * NB, 3 + NX, 3, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CO == 64) {
-            if (n_issue == 2) {
-                db_issue_chunk(ring, a, smem, wave, pvoff);
-                DB_LOAD_W(w2, 2);
-                DB_LOAD_X(x2, 2);
-                DB_MMA(w1, x1);
-                DB_INTERLEAVE(3 * NB, 3 + NX, 3, 1);
-            } else {
-                DB_LOAD_W(w2, 2);
-                DB_LOAD_X(x2, 2);
-                DB_MMA(w1, x1);
-                DB_INTERLEAVE(3 * NB, 3 + NX, 0, 1);
-            }
+        constexpr int SIDE_VALU = (50 + 3 * NB - 1) / (3 * NB);   // half a row's epilogue over the column's MFMAs
+        if (NBP > 0 && t < NBP) {
+            db_growth_quads<JP, 0, 2, GATED>(pacc[t < NBP ? t : 0], praw[t < 3 ? t : 0], braw, i0p + t, c);
+            DB_INTERLEAVE_V(3 * NB, 3 + NX, 3, SIDE_VALU, 0);
         } else {
-            DB_LOAD_W(w2, 2);
-            DB_LOAD_X(x2, 2);
-            DB_MMA(w1, x1);
+            DB_INTERLEAVE(3 * NB, 3 + NX, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // column 1 under the reads of column 2 (conv5: the stage's second refill; the other half of the epilogue row)
+        const bool second_issue = CO == 64 && t > 0;
+        if (second_issue) db_issue_chunk(ring, a, smem, c.wave, c.pvoff);
+        DB_LOAD_W(w2, 2);
+        DB_LOAD_X(x2, 2);
+        DB_MMA(w1, x1);
+        if (NBP > 0 && t < NBP) {
+            db_growth_quads<JP, 2, 4, GATED>(pacc[t < NBP ? t : 0], praw[t < 3 ? t : 0], braw, i0p + t, c);
+            if (second_issue) {
+                DB_INTERLEAVE_V(3 * NB, 3 + NX, 3, SIDE_VALU, 1);
+            } else {
+                DB_INTERLEAVE_V(3 * NB, 3 + NX, 0, SIDE_VALU, 1);
+            }
+        } else if (second_issue) {
+            DB_INTERLEAVE(3 * NB, 3 + NX, 3, 1);
+        } else {
             DB_INTERLEAVE(3 * NB, 3 + NX, 0, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NBP > 0) {
+            if (t == COPY_STAGE && a.growth_out) {
+                // growth array JP is complete since this stage's barrier: the band's own rows go to the block buffer,
+                // one 16-byte item a thread (4 units x 2 rows x 32 pixels)
+                const int u = c.tid >> 6, row = (c.tid >> 5) & 1, px = c.tid & 31;
+                const int y = c.y0 + row;
+                const uint4 val = db_lds_read16(smem + base_of(JP) + ((u * rows_of(JP) + (5 - JP) + row) * DB_P + px + 1) * 16);
+                if (y < c.H && px < c.W)
+                    *reinterpret_cast<uint4 *>(a.growth_out + (size_t)c.n * c.img_bytes +
+                                               ((size_t)(y * a.units + 8 + 4 * (JP - 1) + u) * c.W + px) * 16) = val;
+            }
+        }
         if (t + 1 < S) {
             pa = stage_ptr(t + 1);
             DB_LOAD_X(x0, 0);
@@ -263,76 +332,48 @@ __device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], DbRing &ring, int &c_
 #undef DB_MMA
 }
 
-// Epilogue of a growth step: bias, LeakyReLU, sign gate, zero outside the image, bf16 into the step's LDS array.
-template <int J, int NB>
-__device__ __forceinline__ void db_growth_store(const f32x16 (&acc)[NB], const DenseArgs &a, unsigned char *smem,
-                                                const unsigned (&mbits)[3], int i0, int y0, int r, int h) {
-    const float slope = a.slope, mslope = a.mask_slope;
-    const bool gated = a.mask != nullptr;
-    uint4 braw[4];   // this lane's 16 bias values: channels q*8 + h*4 + j
-    db_lds_read16x4(smem + DB_BIAS_OFF + (J - 1) * 256 + h * 16, 32, braw);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int y = y0 - (5 - J) + i0 + i;
-        const bool ok = y >= 0 && y < a.H && r < a.W;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = __builtin_bit_cast(float4, braw[q]);
-            const float v[4] = {acc[i][4 * q + 0] + bv.x, acc[i][4 * q + 1] + bv.y, acc[i][4 * q + 2] + bv.z,
-                                acc[i][4 * q + 3] + bv.w};
-            bf16x4 pk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = v[j] > 0.f ? v[j] : v[j] * slope;
-                if (gated) t = ((mbits[i] >> (4 * q + j)) & 1u) ? t : t * mslope;
-                pk[j] = (__bf16)(ok ? t : 0.f);
-            }
-            *reinterpret_cast<bf16x4 *>(smem + base_of(J) + ((q * rows_of(J) + i0 + i) * DB_P + r + 1) * 16 + h * 8) = pk;
-        }
-    }
+// The five convs for a wave that holds NB1..NB4 rows of the growth steps (waves 0, 1: 3 2 2 1; waves 2, 3: 2 2 1 1).
+template <int NB1, int NB2, int NB3, int NB4, bool GATED>
+__device__ __forceinline__ void db_run(DbRing &ring, const DbCtx &c, const v2u (&mraw)[4][3][4]) {
+    const int wave = c.wave;
+    [[maybe_unused]] const DenseArgs &a = c.a;
+    int c_slot = 0;   // ring slot of the chunk consumed next
+    int i01, i02, i03, i04, nb_;
+    wave_rows(rows_of(1), wave, i01, nb_);
+    wave_rows(rows_of(2), 3 - wave, i02, nb_);
+    wave_rows(rows_of(3), wave, i03, nb_);
+    wave_rows(rows_of(4), 3 - wave, i04, nb_);
+#define DB_ZERO(ACC, N)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i) _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[i][e] = 0.f;
+    f32x16 acc1[NB1], acc2[NB2], acc3[NB3], acc4[NB4], acc5[1];
+    DB_ZERO(acc1, NB1);
+    db_conv<1, NB1, 32, 0, 0, GATED>(acc1, acc5, mraw[0], 0, ring, c_slot, c, i01, 0);   // (acc5, mraw[0]: unused)
+    DB_STAMP(3);
+    DB_ZERO(acc2, NB2);
+    db_conv<2, NB2, 32, 1, NB1, GATED>(acc2, acc1, mraw[0], i01, ring, c_slot, c, i02, 0);
+    DB_STAMP(5);
+    DB_ZERO(acc3, NB3);
+    db_conv<3, NB3, 32, 2, NB2, GATED>(acc3, acc2, mraw[1], i02, ring, c_slot, c, i03, 0);
+    DB_STAMP(7);
+    DB_ZERO(acc4, NB4);
+    db_conv<4, NB4, 32, 3, NB3, GATED>(acc4, acc3, mraw[2], i03, ring, c_slot, c, i04, 0);
+    DB_STAMP(9);
+    // step 5: 192 -> 64 on the band's two rows; wave = (row, 32-output block)
+    const int row5 = wave & 1, mb5 = wave >> 1;
+    DB_ZERO(acc5, 1);
+    db_conv<5, 1, 64, 4, NB4, GATED>(acc5, acc4, mraw[3], i04, ring, c_slot, c, row5, mb5);
+    DB_STAMP(10);
+    epi_f32x16 acc_t[1][1];
+    acc_t[0][0] = acc5[0];
+    conv_epilogue_tile<1, 1>(c.a.tail, acc_t, c.smem + DB_BIAS_OFF + 4 * 256 + mb5 * 128, c.n, c.y0 + row5, c.r, mb5 * 32,
+                             c.h, true);
+#undef DB_ZERO
 }
 
-template <int J>
-__device__ __forceinline__ void db_growth_step(DbRing &ring, int &c_slot, const DenseArgs &a, unsigned char *smem,
-                                               int tid, int wave, int r, int h, const int (&pvoff)[3],
-                                               const unsigned (&mbits)[3], int n, int y0, int img_bytes) {
-    int i0, nb;
-    wave_rows(rows_of(J), (J & 1) ? wave : 3 - wave, i0, nb);
-    // rows per wave: step 1 -> 3 3 2 2, step 2 -> 2 2 2 2, step 3 -> 2 2 1 1, step 4 -> 1 1 1 1
-    constexpr int NB_HI = (rows_of(J) + 3) / 4, NB_LO = rows_of(J) / 4;
-    if (nb == NB_HI) {
-        f32x16 acc[NB_HI];
-#pragma unroll
-        for (int i = 0; i < NB_HI; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        db_conv<J, NB_HI, 32>(acc, ring, c_slot, a, smem, wave, r, h, pvoff, i0, 0);
-        DB_STAMP(2 * J);
-        db_growth_store<J, NB_HI>(acc, a, smem, mbits, i0, y0, r, h);
-    } else if constexpr (NB_LO != NB_HI) {
-        f32x16 acc[NB_LO];
-#pragma unroll
-        for (int i = 0; i < NB_LO; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-        db_conv<J, NB_LO, 32>(acc, ring, c_slot, a, smem, wave, r, h, pvoff, i0, 0);
-        DB_STAMP(2 * J);
-        db_growth_store<J, NB_LO>(acc, a, smem, mbits, i0, y0, r, h);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (a.growth_out) {   // the band's own rows go to the block buffer: 4 units x 2 rows x 32 pixels, one item a thread
-        const int u = tid >> 6, row = (tid >> 5) & 1, px = tid & 31;
-        const int y = y0 + row;
-        if (y < a.H && px < a.W) {
-            const uint4 val = db_lds_read16(smem + base_of(J) + ((u * rows_of(J) + (5 - J) + row) * DB_P + px + 1) * 16);
-            *reinterpret_cast<uint4 *>(a.growth_out + (size_t)n * img_bytes +
-                                       ((size_t)(y * a.units + 8 + 4 * (J - 1) + u) * a.W + px) * 16) = val;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) {
+// GATED: the data-gradient form (sign gates on steps 1..4); two kernels rather than one with both paths, which ran
+// 1.5 x slower in either form.
+template <bool GATED>
+__device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -353,8 +394,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) {
         0, __builtin_amdgcn_readfirstlane(LEN), 0x00020000)
 
     // ---- pull the block's packed weights (468 KiB) into this XCD's L2 ahead of the ring.  Consecutive dense blocks
-    // use different weights, so the ring's first touch of every line would miss L2 and the four chunks it keeps in
-    // flight would bound the whole kernel by the latency of the next cache level.  Workgroups b and b + 8 usually
+    // use different weights, so the ring's first touch of every line would miss L2.  Workgroups b and b + 8 usually
     // share an XCD (round-robin placement; a speed assumption only): the waves of such a group touch disjoint 1 KiB
     // pieces, one dword per 16 bytes, and drop the result.
     {
@@ -377,7 +417,8 @@ __global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) {
         constexpr int G_UNIT_ROWS = 4 * (rows_of(1) + rows_of(2) + rows_of(3) + rows_of(4));
         if (tid < 2 * G_UNIT_ROWS) {
             const int ur = tid >> 1, side = tid & 1;
-            *reinterpret_cast<uint4 *>(smem + base_of(1) + ur * DB_ROWB + side * (DB_P - 1) * 16) = make_uint4(0, 0, 0, 0);
+            constexpr int G_BASE = base_of(1);
+            *reinterpret_cast<uint4 *>(smem + G_BASE + ur * DB_ROWB + side * (DB_P - 1) * 16) = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -414,86 +455,56 @@ __global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) {
     ring.w_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.w[0]);
     ring.w_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.w[0] >> 32));
     ring.w_len = 4 * DB_CHUNK;
-    int pvoff[3];
+    DbCtx ctx = {a, smem, tid, wave, r, h, n, y0, img_bytes, {}, a.slope, a.mask_slope, H, W};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pvoff[k] = (wave + 4 * k) < 9 ? (wave + 4 * k) * 1024 + lane * 16 : DB_OOB;
+    for (int k = 0; k < 3; ++k) ctx.pvoff[k] = (wave + 4 * k) < 9 ? (wave + 4 * k) * 1024 + lane * 16 : DB_OOB;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) db_issue_chunk(ring, a, smem, wave, pvoff);
-    int c_slot = 0;   // ring slot of the chunk consumed next
+    for (int k = 0; k < 4; ++k) db_issue_chunk(ring, a, smem, wave, ctx.pvoff);
 
-    // ---- sign masks (data-gradient use): bit (4q + j) of mbits[J-1][i] = the saved activation of channel
-    // q*8 + h*4 + j at this lane's pixel of row i of step J is positive.  Loaded behind the prologue's DMA and turned into
-    // bits before the first barrier: the wait on them is the wait on the input tile, and no later wait on them drains
-    // the weight ring.
-    unsigned mbits[4][3] = {};
-    if (a.mask) {
+    // ---- sign gates (data-gradient use): the saved activations at this wave's output pixels of the four growth steps,
+    // 4 channels x 4 quads per row.  Loaded behind the prologue's DMA: the wait on them is the wait on the input tile,
+    // and no later use of them waits on the weight ring.
+    v2u mraw[4][3][4] = {};
+    if constexpr (GATED) {
         const __amdgpu_buffer_rsrc_t rs_mk =
             DB_RSRC(a.mask + (size_t)n * ((size_t)H * a.mask_units * W * 16), H * a.mask_units * W * 16);
-        v2u raw[4][3][4];
+        const int q_step = __builtin_amdgcn_readfirstlane(W * 16);   // one unit further in the mask buffer
 #pragma unroll
         for (int J = 1; J <= 4; ++J) {
             int i0, nb;
             wave_rows(rows_of(J), (J & 1) ? wave : 3 - wave, i0, nb);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int y = y0 - (5 - J) + i0 + i;
-                const bool ok = i < nb && y >= 0 && y < H && r < W;
+                if (i < nb) {   // (wave-uniform)
+                    const int y = y0 - (5 - J) + i0 + i;
+                    const bool ok = y >= 0 && y < H && r < W;
+                    const int vo = ok ? ((y * a.mask_units + a.mask_off[J - 1]) * W + r) * 16 + h * 8 : DB_OOB;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int vo = ok ? ((y * a.mask_units + a.mask_off[J - 1] + q) * W + r) * 16 + h * 8 : DB_OOB;
-                    raw[J - 1][i][q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo, 0, 0);
+                    for (int q = 0; q < 4; ++q) mraw[J - 1][i][q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo, q * q_step, 0);
                 }
             }
         }
-#pragma unroll
-        for (int J = 0; J < 4; ++J)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                unsigned bits = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x4 mv = __builtin_bit_cast(bf16x4, raw[J][i][q]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bits |= ((float)mv[j] > 0.f ? 1u : 0u) << (4 * q + j);
-                }
-                mbits[J][i] = bits;
-            }
     }
 
-
-    // the input tile and the zero columns are in place before the first activation fragments are read (the
-    // fragment prefetch of a step runs ahead of that step's first ring barrier)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (in a gradient launch the mask loads above are the youngest)
+    // the input tile, the zero columns (and the gates) are in place before the first activation fragments are read
+    // (the fragment prefetch of a step runs ahead of that step's first ring barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     DB_STAMP(1);
 
-    db_growth_step<1>(ring, c_slot, a, smem, tid, wave, r, h, pvoff, mbits[0], n, y0, img_bytes);
-    DB_STAMP(3);
-    db_growth_step<2>(ring, c_slot, a, smem, tid, wave, r, h, pvoff, mbits[1], n, y0, img_bytes);
-    DB_STAMP(5);
-    db_growth_step<3>(ring, c_slot, a, smem, tid, wave, r, h, pvoff, mbits[2], n, y0, img_bytes);
-    DB_STAMP(7);
-    db_growth_step<4>(ring, c_slot, a, smem, tid, wave, r, h, pvoff, mbits[3], n, y0, img_bytes);
-    DB_STAMP(9);
-
-    // ---- step 5: 192 -> 64 on the band's two rows; wave = (row, 32-output block)
-    {
-        const int row5 = wave & 1, mb5 = wave >> 1;
-        f32x16 acc5[1];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc5[0][e] = 0.f;
-        db_conv<5, 1, 64>(acc5, ring, c_slot, a, smem, wave, r, h, pvoff, row5, mb5);
-        DB_STAMP(10);
-        epi_f32x16 acc_t[1][1];
-        acc_t[0][0] = acc5[0];
-        conv_epilogue_tile<1, 1>(a.tail, acc_t, smem + DB_BIAS_OFF + 4 * 256 + mb5 * 128, n, y0 + row5, r, mb5 * 32, h, true);
-    }
+    if (wave < 2)
+        db_run<3, 2, 2, 1, GATED>(ring, ctx, mraw);
+    else
+        db_run<2, 2, 1, 1, GATED>(ring, ctx, mraw);
     // the padding chunks still in flight must land before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DB_STAMP(11);
 #undef DB_RSRC
 }
+
+__global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) { dense_block_body<false>(a); }
+__global__ __launch_bounds__(256, 1) void dense_block_band_gated(const DenseArgs a) { dense_block_body<true>(a); }
 
 bool dense_block_supported(int nf, int gc, int dtype, int W) {
     return dtype == SR355_DTYPE_BF16 && nf == 64 && gc == 32 && W >= 1 && W <= 32;
@@ -501,6 +512,10 @@ bool dense_block_supported(int nf, int gc, int dtype, int W) {
 
 int launch_dense_block(const DenseArgs &a0, hipStream_t stream) {
     DenseArgs a = a0;
+    if (!(a.slope >= 0.f && a.slope <= 1.f)) {
+        set_error("dense block: the LeakyReLU slope %g is outside [0, 1]", (double)a.slope);
+        return SR355_ERR_UNSUPPORTED;
+    }
     if (a.units != 24 || a.W < 1 || a.W > 32 || a.H < 1 || a.N < 1 || !a.buf || a.tail.out_nchw || a.tail.out_u8 ||
         a.tail.cout_real != 64) {
         set_error("dense block: needs a 24-unit bf16 block buffer, images at most 32 pixels wide and a 64-channel "
@@ -522,9 +537,15 @@ int launch_dense_block(const DenseArgs &a0, hipStream_t stream) {
     std::call_once(once[dev], [&] {
         attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_block_band),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS_BYTES);
+        if (attr_err[dev] == hipSuccess)
+            attr_err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_block_band_gated),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS_BYTES);
     });
     if (check_hip(attr_err[dev], "hipFuncSetAttribute(dense_block_band)")) return SR355_ERR_HIP;
-    hipLaunchKernelGGL(dense_block_band, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream, a);
+    if (a.mask)
+        hipLaunchKernelGGL(dense_block_band_gated, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL(dense_block_band, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream, a);
     return check_hip(hipGetLastError(), "dense block launch");
 }
 
