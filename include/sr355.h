@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 9
+#define SR355_ABI_VERSION 10
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -125,6 +125,14 @@ typedef struct sr355_conv_args {
      * (esrgan_model.py:24) runs without an fp32 carrier.  Exclusive with res1_dev. */
     const void *res_act_dev; size_t res_act_bytes;
     int res_act_units;
+    /* Stride (0 or 1: stride 1).  2 = nn.Conv2d(c_in, c_out, 3, 2, 1), the discriminator's down-sampling convs
+     * (esrgan_model.py:67-84), bf16, unsplit weights, no upsample: the input is in_H x in_W pixels and the output
+     * H = (in_H+1)/2, W = (in_W+1)/2; computed at the output positions only. */
+    int stride, in_H, in_W;
+    /* With upsample = 1: the input (stored at (H+1)/2 x (W+1)/2) is read as its zero-inserted x2 image (its value at
+     * even y and x, zero elsewhere) instead of its nearest-neighbour one.  On transposed weights this is the data
+     * gradient of a stride-2 conv whose input has H x W pixels (what autograd runs for esrgan_model.py:67-84). */
+    int zero_insert;
 } sr355_conv_args;
 
 int sr355_conv3x3_fwd(const sr355_conv_args *args, void *stream);
@@ -196,6 +204,8 @@ typedef struct sr355_wgrad_args {
     float *dw_dev; size_t dw_bytes;
     float *db_dev;             /* may be NULL */
     void *workspace_dev; size_t workspace_bytes;
+    int dy_stride2;            /* 1: weight gradient of a stride-2 conv whose input has H x W pixels: dy is stored at
+                                  (H+1)/2 x (W+1)/2 (no upsample) */
 } sr355_wgrad_args;
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
@@ -211,6 +221,43 @@ int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
  * sr355_conv3x3_wgrad's. */
 #define SR355_STATIC_SCRATCH_BYTES (16u << 20)
 int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *args, void *stream);
+
+/* ---- BatchNorm2d + LeakyReLU behind a conv (the discriminator's conv_block, esrgan_model.py:67-72) ----
+ * x_f32 is the conv's fp32 output [N][H][C/4][W][4] (sr355_conv3x3_fwd's out_f32_dev; C a multiple of 8).
+ * training = 1: batch statistics over N, H, W (two passes, fixed summation order), running_mean / running_var /
+ * num_batches_tracked updated as nn.BatchNorm2d does (momentum, unbiased variance; any of them may be NULL);
+ * training = 0: the running statistics.  save_mean / save_rstd [C] receive what the backward pass needs.  The output
+ * is blocked bf16 at out_unit_off: y = lrelu(gamma * (x - mean) * rstd + beta). */
+size_t sr355_bn_workspace_bytes(int N, int H, int W, int C);
+int sr355_bn_lrelu_fwd(const float *x_f32_dev, size_t x_bytes, int N, int H, int W, int C, const float *gamma_dev,
+                       const float *beta_dev, float eps, float lrelu_slope, int training, float momentum,
+                       float *running_mean_dev, float *running_var_dev, long long *num_batches_tracked_dev,
+                       float *save_mean_dev, float *save_rstd_dev, void *out_act_dev, size_t out_act_bytes,
+                       int out_units, int out_unit_off, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* Its backward pass (autograd of the same lines): dy_act = gradient of the output (blocked bf16); dx_act (blocked bf16,
+ * the layout the conv's data / weight gradients read) = gradient of x; dgamma / dbeta [C] overwritten. */
+int sr355_bn_lrelu_bwd(const float *x_f32_dev, size_t x_bytes, const void *dy_act_dev, size_t dy_bytes, int dy_units,
+                       int dy_unit_off, int N, int H, int W, int C, const float *gamma_dev, const float *beta_dev,
+                       const float *save_mean_dev, const float *save_rstd_dev, float lrelu_slope, int training,
+                       void *dx_act_dev, size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma_dev,
+                       float *dbeta_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- nn.MaxPool2d(2, 2) on blocked bf16 (vgg19.features' pooling layers, esrgan_model.py:93-98) ----
+ * in [N][H][units][W] -> out [N][H/2][units][W/2] (an odd trailing row / column is dropped).  The backward pass
+ * recomputes the argmax from the forward input: the whole gradient goes to the first maximum of a window in row-major
+ * order (nn.MaxPool2d's rule); dx is written in full. */
+int sr355_maxpool2x2_fwd(const void *in_act_dev, size_t in_bytes, int N, int H, int W, int units, void *out_act_dev,
+                         size_t out_bytes, void *stream);
+int sr355_maxpool2x2_bwd(const void *in_act_dev, size_t in_bytes, const void *dy_act_dev, size_t dy_bytes, int N, int H,
+                         int W, int units, void *dx_act_dev, size_t dx_bytes, void *stream);
+
+/* ---- nn.L1Loss / nn.MSELoss (mean reduction) of the training iteration (train.py:114-115, :160, :201-204, :214-219)
+ * mode 0: mean |a - b|; mode 1: mean (a - b)^2 over n fp32 elements; b_dev == NULL: the constant b_const (the
+ * ones / zeros targets of the adversarial terms).  grad_dev (optional) receives d(loss)/da in the same pass, so the
+ * backward pass is one scale by the incoming gradient.  Deterministic (per-workgroup partials, fixed order). */
+size_t sr355_loss_workspace_bytes(size_t n);
+int sr355_loss_fwd(const float *a_dev, const float *b_dev, float b_const, size_t n, int mode, float *loss_dev,
+                   float *grad_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- whole generator (GeneratorRRDB.forward, esrgan_model.py:55-62) ---- */
 typedef struct sr355_generator_cfg {

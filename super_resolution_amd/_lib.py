@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -38,6 +38,8 @@ EXPORTS = (
     "sr355_generator_grads_floats", "sr355_generator_backward",
     "sr355_generator_backward_phases", "sr355_generator_backward_range",
     "sr355_adam_step",
+    "sr355_bn_workspace_bytes", "sr355_bn_lrelu_fwd", "sr355_bn_lrelu_bwd",
+    "sr355_maxpool2x2_fwd", "sr355_maxpool2x2_bwd", "sr355_loss_workspace_bytes", "sr355_loss_fwd",
 )
 
 
@@ -61,6 +63,7 @@ class ConvArgs(C.Structure):
         ("out_nchw_dev", C.c_void_p), ("out_nchw_bytes", C.c_size_t),
         ("f16_in", C.c_int), ("f16_out", C.c_int),
         ("res_act_dev", C.c_void_p), ("res_act_bytes", C.c_size_t), ("res_act_units", C.c_int),
+        ("stride", C.c_int), ("in_H", C.c_int), ("in_W", C.c_int), ("zero_insert", C.c_int),
     ]
 
 
@@ -93,6 +96,7 @@ class WgradArgs(C.Structure):
         ("cout", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
         ("dw_dev", C.c_void_p), ("dw_bytes", C.c_size_t), ("db_dev", C.c_void_p),
         ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dy_stride2", C.c_int),
     ]
 
 
@@ -171,6 +175,15 @@ def lib() -> C.CDLL:
     L.sr355_generator_backward.argtypes = [cfgp, vp, sz, vp, sz, vp, vp, sz, vp, i, i, i, vp, sz, vp]
     L.sr355_generator_backward_phases.argtypes = [cfgp]
     L.sr355_generator_backward_range.argtypes = [cfgp, vp, sz, vp, sz, vp, vp, sz, vp, i, i, i, vp, sz, i, i, vp]
+    L.sr355_bn_workspace_bytes.argtypes = [i, i, i, i]
+    L.sr355_bn_workspace_bytes.restype = sz
+    L.sr355_bn_lrelu_fwd.argtypes = [vp, sz, i, i, i, i, vp, vp, f, f, i, f, vp, vp, vp, vp, vp, vp, sz, i, i, vp, sz, vp]
+    L.sr355_bn_lrelu_bwd.argtypes = [vp, sz, vp, sz, i, i, i, i, i, i, vp, vp, vp, vp, f, i, vp, sz, i, i, vp, vp, vp, sz, vp]
+    L.sr355_maxpool2x2_fwd.argtypes = [vp, sz, i, i, i, i, vp, sz, vp]
+    L.sr355_maxpool2x2_bwd.argtypes = [vp, sz, vp, sz, i, i, i, i, vp, sz, vp]
+    L.sr355_loss_workspace_bytes.argtypes = [sz]
+    L.sr355_loss_workspace_bytes.restype = sz
+    L.sr355_loss_fwd.argtypes = [vp, vp, f, sz, i, vp, vp, vp, sz, vp]
     if L.sr355_abi_version() != ABI_VERSION:
         raise Sr355Error(f"libsr355.so ABI {L.sr355_abi_version()} != expected {ABI_VERSION}; rebuild")
     _lib = L

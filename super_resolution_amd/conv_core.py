@@ -6,9 +6,10 @@ channel widths, strides and epilogues than the generator's.  They reuse the gene
 this Function: activations stay in the blocked bf16 layout between layers, the forward is
 ``sr355::conv3x3_fwd`` (bias and LeakyReLU/ReLU fused), the data gradient is the same kernel on the
 transposed weights and the weight/bias gradient is ``sr355::conv3x3_wgrad`` in blocks of 64 output
-channels.  A stride-2 convolution is the stride-1 result sampled at even positions (same arithmetic as
-``nn.Conv2d(k=3, s=2, p=1)``, four times the work); BatchNorm and pooling run as torch ops on views of the
-blocked tensors.
+channels.  A stride-2 convolution (``nn.Conv2d(k=3, s=2, p=1)``) is computed at its output positions only; its data
+and weight gradients read the output gradient as its zero-inserted x2 image through the same kernels.  BatchNorm +
+LeakyReLU behind a conv (``conv_bn_act``), 2x2 max pooling (``max_pool2x2``) and the mean L1 / MSE losses
+(``l1_loss`` / ``mse_loss``) are HIP kernels on the same layout, forward and backward.
 """
 from __future__ import annotations
 
@@ -102,48 +103,83 @@ def _packs_of(weight: Tensor) -> _PackedWeights:
     return p
 
 
+def _conv_forward(x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kind: str, stride: int) -> Tensor:
+    """One conv launch: blocked bf16 in, ``out_kind`` out ("blocked" bf16, "f32" [N,H,C/4,W,4], "nchw" fp32)."""
+    if x.dtype != torch.bfloat16 or x.dim() != 5 or not x.is_contiguous():
+        raise RuntimeError("conv3x3: expected a contiguous blocked bf16 tensor [N, H, units, W, 8]")
+    if stride not in (1, 2):
+        raise RuntimeError(f"conv3x3: stride {stride} is not supported (1 or 2)")
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    N, Hi, U, Wi, _ = x.shape
+    H, W = ((Hi + 1) // 2, (Wi + 1) // 2) if stride == 2 else (Hi, Wi)
+    if U < units_for(cin):
+        raise RuntimeError(f"conv3x3: input has {U} units, the weight needs {units_for(cin)}")
+    wp, bp = _packs_of(weight).forward_pack(weight, bias)
+    out_act = out_f32 = out_nchw = None
+    if out_kind == "nchw":
+        y = out_nchw = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
+    elif out_kind == "f32":
+        if cout % 16 or slope != 1.0:
+            raise RuntimeError("conv3x3: fp32 outputs need a multiple of 16 channels and no fused activation")
+        y = out_f32 = torch.empty((N, H, cout // 4, W, 4), dtype=torch.float32, device=x.device)
+    elif out_kind == "blocked":
+        if cout % 4:
+            raise RuntimeError("conv3x3: blocked outputs need a multiple of 4 output channels")
+        # the kernel writes every real channel of every pixel: only padding channels need the zero fill
+        alloc = torch.empty if units_for(cout) * 8 == cout else torch.zeros
+        y = out_act = alloc((N, H, units_for(cout), W, 8), dtype=torch.bfloat16, device=x.device)
+    else:
+        raise RuntimeError(f"conv3x3: unknown output kind {out_kind!r}")
+    if stride == 1:
+        ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, out_act, 0, out_f32,
+                            out_nchw)
+    else:
+        ops.launch_conv(ops.conv_args(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, out_act, 0,
+                                      out_f32, out_nchw, stride=2))
+    return y
+
+
+def _conv_backward(x: Tensor, weight: Tensor, bias: Tensor, dyb: Tensor, stride: int, need_dx: bool, need_dw: bool):
+    """Data / weight / bias gradients of one conv from the blocked bf16 gradient ``dyb`` of its (pre-activation)
+    output.  Stride 2: the data gradient reads ``dyb`` as its zero-inserted x2 image, the weight gradient likewise."""
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    N, H, U, W, _ = x.shape
+    dx = dw = db = None
+    if need_dx:
+        wt, zero_bias = _packs_of(weight).backward_pack(weight, bias)
+        n_out = (cin + 3) // 4 * 4
+        alloc = torch.empty if U * 8 == n_out else torch.zeros
+        dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
+        if stride == 1:
+            ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
+        else:
+            ops.launch_conv(ops.conv_args(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 1, None, 0.0, None, 0.0, dx, 0,
+                                          None, None, zero_insert=True))
+    if need_dw:
+        dw = torch.empty_like(weight, dtype=torch.float32)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+        ops.conv3x3_wgrad_all(x, cin, dyb, cout, dw, db, stride=stride)   # 64 output channels a kernel call, looped inside
+    return dx, dw, db
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kind: str) -> Tensor:
-        if x.dtype != torch.bfloat16 or x.dim() != 5 or not x.is_contiguous():
-            raise RuntimeError("conv3x3: expected a contiguous blocked bf16 tensor [N, H, units, W, 8]")
-        cout, cin = int(weight.shape[0]), int(weight.shape[1])
-        N, H, U, W, _ = x.shape
-        if U < units_for(cin):
-            raise RuntimeError(f"conv3x3: input has {U} units, the weight needs {units_for(cin)}")
-        wp, bp = _packs_of(weight).forward_pack(weight, bias)
-        nchw_out = out_kind == "nchw"
-        if out_kind not in ("blocked", "nchw", "f32"):
-            raise RuntimeError(f"conv3x3: unknown output kind {out_kind!r}")
-        if nchw_out:
-            y = torch.empty((N, cout, H, W), dtype=torch.float32, device=x.device)
-            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, None, 0, None, y)
-        elif out_kind == "f32":
-            if cout % 16 or slope != 1.0:
-                raise RuntimeError("conv3x3: fp32 outputs need a multiple of 16 channels and no fused activation")
-            y = torch.empty((N, H, cout // 4, W, 4), dtype=torch.float32, device=x.device)
-            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, 1.0, 0, None, 0.0, None, 0.0, None, 0, y, None)
-        else:
-            if cout % 4:
-                raise RuntimeError("conv3x3: blocked outputs need a multiple of 4 output channels")
-            # the kernel writes every real channel of every pixel: only padding channels need the zero fill
-            alloc = torch.empty if units_for(cout) * 8 == cout else torch.zeros
-            y = alloc((N, H, units_for(cout), W, 8), dtype=torch.bfloat16, device=x.device)
-            ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, float(slope), 0, None, 0.0, None, 0.0, y, 0, None, None)
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kind: str, stride: int) -> Tensor:
+        y = _conv_forward(x, weight, bias, slope, out_kind, stride)
         ctx.save_for_backward(x, weight, bias, y if (slope != 1.0 and out_kind == "blocked") else None)
-        ctx.slope, ctx.out_kind = float(slope), out_kind
+        ctx.slope, ctx.out_kind, ctx.stride = float(slope), out_kind, stride
         return y
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         x, weight, bias, y = ctx.saved_tensors
-        cout, cin = int(weight.shape[0]), int(weight.shape[1])
-        N, H, U, W, _ = x.shape
+        cout = int(weight.shape[0])
         if ctx.out_kind == "nchw":
             if ctx.slope != 1.0:
                 raise RuntimeError("conv3x3: an NCHW output carries no fused activation")
             dyb = ops.to_blocked_now(dy.float().contiguous(), units_for(cout), DTYPE_BF16)
         elif ctx.out_kind == "f32":                 # [N,H,C/4,W,4] fp32 -> [N,H,C/8,W,8] bf16
+            N, H, _q, W, _c = dy.shape
             dyb = dy.reshape(N, H, cout // 8, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, cout // 8, W, 8)
             dyb = dyb.to(torch.bfloat16).contiguous()
         else:
@@ -152,27 +188,65 @@ class _Conv3x3(torch.autograd.Function):
                 # (the output has the sign of the pre-activation, so it can stand in for it)
                 dyb = (torch.ops.aten.threshold_backward(dyb, y, 0.0) if ctx.slope == 0.0
                        else torch.ops.aten.leaky_relu_backward(dyb, y, ctx.slope, False))
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt, zero_bias = _packs_of(weight).backward_pack(weight, bias)
-            n_out = (cin + 3) // 4 * 4
-            alloc = torch.empty if U * 8 == n_out else torch.zeros
-            dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
-            ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight, dtype=torch.float32)
-            db = torch.empty((cout,), dtype=torch.float32, device=x.device)
-            ops.conv3x3_wgrad_all(x, cin, dyb, cout, dw, db)     # 64 output channels a kernel call, looped inside
-        return dx, dw, db, None, None
+        dx, dw, db = _conv_backward(x, weight, bias, dyb, ctx.stride, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, None, None, None
 
 
 def conv3x3(x: Tensor, weight: Tensor, bias: Tensor, slope: float = 1.0, nchw_out: bool = False,
-            f32_out: bool = False) -> Tensor:
-    """3x3 / stride 1 / pad 1 convolution of a blocked bf16 tensor with an OIHW fp32 weight.  ``slope`` is the
+            f32_out: bool = False, stride: int = 1) -> Tensor:
+    """3x3 / pad 1 convolution (stride 1 or 2) of a blocked bf16 tensor with an OIHW fp32 weight.  ``slope`` is the
     fused LeakyReLU slope (1.0 none, 0.0 ReLU).  The result is blocked bf16 [N,H,units,W,8]; ``nchw_out`` returns
     NCHW fp32 instead, ``f32_out`` the fp32 layout [N,H,C/4,W,4] (what a following normalisation should read:
-    subtracting a batch mean from bf16-rounded values amplifies their rounding)."""
-    return _Conv3x3.apply(x, weight, bias, slope, "nchw" if nchw_out else ("f32" if f32_out else "blocked"))
+    subtracting a batch mean from bf16-rounded values amplifies their rounding).  Stride 2 is computed at the output
+    positions only; its gradients read the output gradient as its zero-inserted x2 image."""
+    return _Conv3x3.apply(x, weight, bias, slope, "nchw" if nchw_out else ("f32" if f32_out else "blocked"), stride)
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """conv3x3 -> BatchNorm2d -> LeakyReLU as the discriminator's ``conv_block`` composes them
+    (/root/reference/esrgan/models/esrgan_model.py:67-72): the conv's fp32 output goes straight into the statistics
+    and normalisation kernels, which write the next layer's blocked bf16 input; the backward pass returns the blocked
+    bf16 gradient the conv's data / weight gradient kernels read.  No layout shuffle on either side."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, gamma: Tensor, beta: Tensor, bn, slope: float,
+                stride: int) -> Tensor:
+        cout = int(weight.shape[0])
+        if cout % 16:
+            raise RuntimeError("conv_bn_act: the normalised layer needs a multiple of 16 channels")
+        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+            raise RuntimeError("conv_bn_act: BatchNorm2d with affine parameters, running statistics and a fixed momentum")
+        y32 = _conv_forward(x, weight, bias, 1.0, "f32", stride)
+        N, H, _q, W, _c = y32.shape
+        training = bool(bn.training)
+        mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(cout, dtype=torch.float32, device=x.device)
+        out = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=x.device)
+        ops.bn_lrelu_fwd_now(y32, gamma.detach(), beta.detach(), float(bn.eps), float(slope), training, float(bn.momentum),
+                             bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, rstd, out, 0)
+        ctx.save_for_backward(x, weight, bias, gamma, beta, y32, mean, rstd)
+        ctx.slope, ctx.stride, ctx.training = float(slope), stride, training
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, weight, bias, gamma, beta, y32, mean, rstd = ctx.saved_tensors
+        cout = int(weight.shape[0])
+        dyb = torch.empty_like(dy, memory_format=torch.contiguous_format)
+        dgamma = torch.empty(cout, dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty(cout, dtype=torch.float32, device=dy.device)
+        ops.bn_lrelu_bwd_now(y32, dy.contiguous(), gamma.detach(), beta.detach(), mean, rstd, ctx.slope, ctx.training,
+                             dyb, dgamma, dbeta, 0, 0)
+        dx, dw, db = _conv_backward(x, weight, bias, dyb, ctx.stride, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, dgamma, dbeta, None, None, None
+
+
+def conv_bn_act(x: Tensor, conv, bn, slope: float) -> Tensor:
+    """``LeakyReLU(slope)(bn(conv(x)))`` for a 3x3 / pad 1 ``nn.Conv2d`` (stride 1 or 2) and an ``nn.BatchNorm2d``,
+    blocked bf16 in and out; the BatchNorm module's mode and running buffers behave as in stock PyTorch."""
+    return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn, slope, int(conv.stride[0]))
 
 
 def f32_as_nchw(y: Tensor) -> Tensor:
@@ -195,34 +269,58 @@ def nchw_as_blocked(v: Tensor) -> Tensor:
 
 class _MaxPool2x2(torch.autograd.Function):
     """nn.MaxPool2d(2, 2) on a blocked tensor with its tie rule: the whole gradient goes to the first maximum of a
-    window in row-major order (bf16 activations tie often)."""
+    window in row-major order (bf16 activations tie often).  Both directions are one HIP kernel; the backward pass
+    recomputes the argmax from the saved input."""
 
     @staticmethod
     def forward(ctx, x: Tensor) -> Tensor:
-        H2, W2 = x.shape[1] // 2 * 2, x.shape[3] // 2 * 2
-        a, b = x[:, 0:H2:2, :, 0:W2:2], x[:, 0:H2:2, :, 1:W2:2]
-        c, d = x[:, 1:H2:2, :, 0:W2:2], x[:, 1:H2:2, :, 1:W2:2]
-        m = torch.maximum(torch.maximum(a, b), torch.maximum(c, d))
-        ia = a == m
-        ib = (b == m) & ~ia
-        ic = (c == m) & ~ia & ~ib
-        ctx.save_for_backward(ia, ib, ic)
-        ctx.shape = x.shape
-        return m.contiguous()
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool2x2_fwd_now(x)
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        ia, ib, ic = ctx.saved_tensors
-        H2, W2 = ctx.shape[1] // 2 * 2, ctx.shape[3] // 2 * 2
-        dx = g.new_zeros(ctx.shape)
-        zero = g.new_zeros(())
-        dx[:, 0:H2:2, :, 0:W2:2] = torch.where(ia, g, zero)
-        dx[:, 0:H2:2, :, 1:W2:2] = torch.where(ib, g, zero)
-        dx[:, 1:H2:2, :, 0:W2:2] = torch.where(ic, g, zero)
-        dx[:, 1:H2:2, :, 1:W2:2] = torch.where(ia | ib | ic, zero, g)
-        return dx
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2x2_bwd_now(x, g.contiguous())
 
 
 def max_pool2x2(x: Tensor) -> Tensor:
     """2x2 / stride 2 max pooling of a blocked tensor (odd trailing rows / columns dropped, as nn.MaxPool2d)."""
     return _MaxPool2x2.apply(x)
+
+
+class _MeanLoss(torch.autograd.Function):
+    """mean |a - b| (mode 0) / mean (a - b)^2 (mode 1) with the gradient factor written by the same kernel pass."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b, b_const: float, mode: int) -> Tensor:
+        need = ctx.needs_input_grad[0] or (isinstance(b, Tensor) and ctx.needs_input_grad[1])
+        loss, grad = ops.loss_fwd_now(a, b, float(b_const), int(mode), bool(need))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (grad,) = ctx.saved_tensors
+        ga = grad * g
+        return (ga if ctx.needs_input_grad[0] else None, -ga if ctx.needs_input_grad[1] else None, None, None)
+
+
+def _loss(a: Tensor, b, mode: int) -> Tensor:
+    a32 = a.float().contiguous()
+    if isinstance(b, Tensor):
+        if b.shape != a.shape:
+            raise RuntimeError(f"loss: shapes differ ({tuple(a.shape)} vs {tuple(b.shape)})")
+        return _MeanLoss.apply(a32, b.float().contiguous(), 0.0, mode)
+    return _MeanLoss.apply(a32, None, float(b), mode)
+
+
+def l1_loss(a: Tensor, b) -> Tensor:
+    """``nn.L1Loss()(a, b)`` (mean reduction) in one reduction kernel; ``b`` may be a Python number."""
+    return _loss(a, b, 0)
+
+
+def mse_loss(a: Tensor, b) -> Tensor:
+    """``nn.MSELoss()(a, b)`` (mean reduction) in one reduction kernel; ``b`` may be a Python number (the ones / zeros
+    targets of the adversarial terms, /root/reference/esrgan/train.py:201-204, :214)."""
+    return _loss(a, b, 1)

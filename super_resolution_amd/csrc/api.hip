@@ -211,11 +211,22 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
                   p->upsample);
         return SR355_ERR_INVALID;
     }
-    if (p->upsample && ((p->H | p->W) & 1)) {
+    if (p->upsample && !p->zero_insert && ((p->H | p->W) & 1)) {
         set_error("conv3x3_fwd: fused x2 upsample needs even output H, W (got %d x %d)", p->H, p->W);
         return SR355_ERR_INVALID;
     }
-    const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
+    const int stride = p->stride ? p->stride : 1;
+    if ((stride != 1 && stride != 2) || (p->zero_insert && (!p->upsample || stride != 1)) ||
+        (stride == 2 && (p->upsample || p->dtype != SR355_DTYPE_BF16 || p->weight_split != SR355_SPLIT_NONE || p->f16_in ||
+                         p->in_H < 1 || p->in_W < 1 || p->H != (p->in_H + 1) / 2 || p->W != (p->in_W + 1) / 2))) {
+        set_error("conv3x3_fwd: stride must be 1 or 2; stride 2 takes a plain bf16 in_H x in_W input with H = (in_H+1)/2, "
+                  "W = (in_W+1)/2 and no upsample; zero_insert goes with upsample = 1 and stride 1 (got stride=%d "
+                  "upsample=%d zero_insert=%d in %dx%d out %dx%d)", stride, p->upsample, p->zero_insert, p->in_H, p->in_W,
+                  p->H, p->W);
+        return SR355_ERR_INVALID;
+    }
+    const int Hin = stride == 2 ? p->in_H : (p->H + (p->zero_insert ? 1 : 0)) >> p->upsample;
+    const int Win = stride == 2 ? p->in_W : (p->W + (p->zero_insert ? 1 : 0)) >> p->upsample;
     if (p->cin_units < 2 || (p->cin_units & 1) || p->cin_units > p->in_units) {
         set_error("conv3x3_fwd: cin_units=%d must be even and within in_units=%d", p->cin_units, p->in_units);
         return SR355_ERR_INVALID;
@@ -332,6 +343,9 @@ int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     a.W = p->W;
     a.in_units = p->in_units;
     a.ups = p->upsample;
+    a.zins = p->zero_insert ? 1 : 0;
+    a.stride = stride;
+    a.in_H = Hin, a.in_W = Win;
     a.out_units = p->out_units;
     a.out_unit_off = p->out_unit_off;
     a.cout_real = p->cout;
@@ -479,7 +493,13 @@ static int wgrad_checks(const char *who, const sr355_wgrad_args *p, const void *
         return SR355_ERR_INVALID;
     }
     const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
-    const size_t in_img = (size_t)Hin * p->in_units * Win * 16, dy_img = (size_t)p->H * p->dy_units * p->W * 16;
+    const int s2 = p->dy_stride2 ? 1 : 0;
+    if (s2 && p->upsample) {
+        set_error("%s: dy_stride2 and upsample exclude each other", who);
+        return SR355_ERR_INVALID;
+    }
+    const size_t in_img = (size_t)Hin * p->in_units * Win * 16;
+    const size_t dy_img = (size_t)((p->H + s2) >> s2) * p->dy_units * ((p->W + s2) >> s2) * 16;
     if (in_img >= ((size_t)1 << 31) || dy_img >= ((size_t)1 << 31)) {
         set_error("%s: one image exceeds the 31-bit offsets of the kernel", who);
         return SR355_ERR_UNSUPPORTED;
@@ -504,7 +524,7 @@ int sr355_conv3x3_wgrad(const sr355_wgrad_args *p, void *stream) {
     if (rc) return rc;
     return launch_wgrad3x3(p->in_dev, p->in_units, p->upsample, p->dy_dev, p->dy_units, p->dy_unit_off, p->N, p->H,
                            p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev, p->db_dev,
-                           (float *)p->workspace_dev, (hipStream_t)stream);
+                           (float *)p->workspace_dev, (hipStream_t)stream, p->dy_stride2);
 }
 
 int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *p, void *stream) {
@@ -519,7 +539,106 @@ int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *p, void *stream) {
     if ((rc = wgrad_checks("conv3x3_wgrad_static", p, scratch, SR355_STATIC_SCRATCH_BYTES))) return rc;
     return launch_wgrad3x3(p->in_dev, p->in_units, p->upsample, p->dy_dev, p->dy_units, p->dy_unit_off, p->N, p->H,
                            p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev, p->db_dev, scratch,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, p->dy_stride2);
+}
+
+// ---- layers around the convs of the discriminator / VGG19, loss reductions ---------------------
+size_t sr355_bn_workspace_bytes(int N, int H, int W, int C) {
+    if (N < 1 || H < 1 || W < 1 || C < 8 || (C & 7)) return 0;
+    return bn_workspace_floats(N, H, W, C) * sizeof(float);
+}
+
+static int bn_checks(const char *who, const float *x, size_t x_bytes, int N, int H, int W, int C, const float *gamma,
+                     const float *beta, const float *mean, const float *rstd, const void *act, size_t act_bytes,
+                     int units, int unit_off, const void *ws, size_t ws_bytes) {
+    if (N < 1 || H < 1 || W < 1 || C < 8 || (C & 7)) {
+        set_error("%s: bad shape N=%d H=%d W=%d C=%d (channels in whole 8-channel units)", who, N, H, W, C);
+        return SR355_ERR_INVALID;
+    }
+    const size_t px = (size_t)N * H * W;
+    if (!x || !aligned16(x) || x_bytes < px * C * 4 || !gamma || !beta || !mean || !rstd) {
+        set_error("%s: fp32 input, gamma / beta or statistics missing, misaligned or too small", who);
+        return SR355_ERR_INVALID;
+    }
+    if (!act || !aligned16(act) || unit_off < 0 || unit_off + C / 8 > units || act_bytes < px * units * 16) {
+        set_error("%s: blocked tensor geometry invalid (off=%d units=%d, %zu bytes)", who, unit_off, units, act_bytes);
+        return SR355_ERR_INVALID;
+    }
+    if (!ws || !aligned16(ws) || ws_bytes < sr355_bn_workspace_bytes(N, H, W, C)) {
+        set_error("%s: workspace missing or smaller than %zu bytes", who, sr355_bn_workspace_bytes(N, H, W, C));
+        return SR355_ERR_INVALID;
+    }
+    return SR355_OK;
+}
+
+int sr355_bn_lrelu_fwd(const float *x_f32, size_t x_bytes, int N, int H, int W, int C, const float *gamma,
+                       const float *beta, float eps, float lrelu_slope, int training, float momentum,
+                       float *running_mean, float *running_var, long long *num_batches_tracked, float *save_mean,
+                       float *save_rstd, void *out_act, size_t out_act_bytes, int out_units, int out_unit_off,
+                       void *workspace, size_t workspace_bytes, void *stream) {
+    const int rc = bn_checks("bn_lrelu_fwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd, out_act,
+                             out_act_bytes, out_units, out_unit_off, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!training && (!running_mean || !running_var)) {
+        set_error("bn_lrelu_fwd: eval mode needs the running statistics");
+        return SR355_ERR_INVALID;
+    }
+    return launch_bn_lrelu_fwd(x_f32, N, H, W, C, gamma, beta, eps, lrelu_slope, training, momentum, running_mean,
+                               running_var, num_batches_tracked, save_mean, save_rstd, out_act, out_units, out_unit_off,
+                               (float *)workspace, (hipStream_t)stream);
+}
+
+int sr355_bn_lrelu_bwd(const float *x_f32, size_t x_bytes, const void *dy_act, size_t dy_bytes, int dy_units,
+                       int dy_unit_off, int N, int H, int W, int C, const float *gamma, const float *beta,
+                       const float *save_mean, const float *save_rstd, float lrelu_slope, int training, void *dx_act,
+                       size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma, float *dbeta, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    int rc = bn_checks("bn_lrelu_bwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd, dy_act, dy_bytes,
+                       dy_units, dy_unit_off, workspace, workspace_bytes);
+    if (rc) return rc;
+    const size_t px = (size_t)N * H * W;
+    if (!dx_act || !aligned16(dx_act) || dx_unit_off < 0 || dx_unit_off + C / 8 > dx_units ||
+        dx_bytes < px * dx_units * 16 || !dgamma || !dbeta) {
+        set_error("bn_lrelu_bwd: dx geometry invalid or dgamma / dbeta missing");
+        return SR355_ERR_INVALID;
+    }
+    return launch_bn_lrelu_bwd(x_f32, dy_act, dy_units, dy_unit_off, N, H, W, C, gamma, beta, save_mean, save_rstd,
+                               lrelu_slope, training, dx_act, dx_units, dx_unit_off, dgamma, dbeta, (float *)workspace,
+                               (hipStream_t)stream);
+}
+
+int sr355_maxpool2x2_fwd(const void *in_act, size_t in_bytes, int N, int H, int W, int units, void *out_act,
+                         size_t out_bytes, void *stream) {
+    if (N < 1 || H < 1 || W < 1 || units < 1 || !in_act || !aligned16(in_act) || !out_act || !aligned16(out_act) ||
+        in_bytes < (size_t)N * H * W * units * 16 || out_bytes < (size_t)N * (H / 2) * (W / 2) * units * 16) {
+        set_error("maxpool2x2_fwd: bad arguments (N=%d H=%d W=%d units=%d)", N, H, W, units);
+        return SR355_ERR_INVALID;
+    }
+    return launch_maxpool2x2_fwd(in_act, N, H, W, units, out_act, (hipStream_t)stream);
+}
+
+int sr355_maxpool2x2_bwd(const void *in_act, size_t in_bytes, const void *dy_act, size_t dy_bytes, int N, int H, int W,
+                         int units, void *dx_act, size_t dx_bytes, void *stream) {
+    if (N < 1 || H < 1 || W < 1 || units < 1 || !in_act || !aligned16(in_act) || !dy_act || !aligned16(dy_act) ||
+        !dx_act || !aligned16(dx_act) || in_bytes < (size_t)N * H * W * units * 16 || dx_bytes < (size_t)N * H * W * units * 16 ||
+        dy_bytes < (size_t)N * (H / 2) * (W / 2) * units * 16) {
+        set_error("maxpool2x2_bwd: bad arguments (N=%d H=%d W=%d units=%d)", N, H, W, units);
+        return SR355_ERR_INVALID;
+    }
+    return launch_maxpool2x2_bwd(in_act, dy_act, N, H, W, units, dx_act, (hipStream_t)stream);
+}
+
+size_t sr355_loss_workspace_bytes(size_t n) { return n ? (size_t)loss_parts(n) * sizeof(float) : 0; }
+
+int sr355_loss_fwd(const float *a, const float *b, float b_const, size_t n, int mode, float *loss_out, float *grad_out,
+                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!a || !aligned16(a) || !aligned16(b) || !aligned16(grad_out) || n < 1 || (mode != 0 && mode != 1) || !loss_out ||
+        !workspace || workspace_bytes < sr355_loss_workspace_bytes(n)) {
+        set_error("loss_fwd: bad arguments (n=%zu mode=%d; tensors 16-byte aligned, workspace >= %zu bytes)", n, mode,
+                  sr355_loss_workspace_bytes(n));
+        return SR355_ERR_INVALID;
+    }
+    return launch_loss(a, b, b_const, n, mode, loss_out, grad_out, (float *)workspace, (hipStream_t)stream);
 }
 
 // ---- generator ----------------------------------------------------------------------------

@@ -1,0 +1,425 @@
+// The layers around the 3x3 convs of the discriminator and of the VGG19 feature extractor, on the blocked layout,
+// and the loss reductions of the training iteration:
+//   * BatchNorm2d (batch statistics in training mode, running statistics in eval mode) + LeakyReLU, forward and
+//     backward: nn.BatchNorm2d(out_f) + nn.LeakyReLU(0.2) of /root/reference/esrgan/models/esrgan_model.py:68-72;
+//   * 2x2 / stride 2 max pooling, forward and backward, with nn.MaxPool2d's tie rule (the gradient goes to the first
+//     maximum of a window in row-major order): vgg19.features' "M" layers, esrgan_model.py:93-98;
+//   * mean |a - b| and mean (a - b)^2 with the gradient factor written in the same pass: nn.L1Loss / nn.MSELoss of
+//     /root/reference/esrgan/train.py:114-115 as used at :160, :201-204, :214-219.
+// All of it is memory-bound elementwise / reduction work: 16-byte accesses, fixed-order two-level sums (per-workgroup
+// partials, then one pass over the partials), no float atomics, so results do not depend on scheduling.
+#include <string.h>
+
+#include "sr355_internal.h"
+
+namespace sr355 {
+
+namespace {
+constexpr int AUX_THREADS = 256;
+constexpr int BN_MAX_PARTS = 64;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    // 256 threads = 4 waves: lanes by shuffles, waves through LDS, in a fixed order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm statistics.  x is an fp32 trunk tensor [rows = N*H][C/4][W][4].  Workgroup (part p, quad cq) sums the
+// rows p, p + parts, ... of the four channels of quad cq.
+__global__ void bn_partial_sum_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
+                                      float *__restrict__ psum /* [parts][4Q] */) {
+    __shared__ float red[4];
+    const int cq = blockIdx.y, p = blockIdx.x;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = p; row < rows; row += parts) {
+        const float4 *src = x + ((size_t)row * Q + cq) * W;
+        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
+            const float4 v = src[i];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    }
+    const float a = block_sum(s.x, red), b = block_sum(s.y, red), c = block_sum(s.z, red), d = block_sum(s.w, red);
+    if (threadIdx.x == 0) {
+        float *o = psum + (size_t)p * 4 * Q + 4 * cq;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
+    }
+}
+
+// Second pass: sum of squared deviations from the mean the first pass gives (two passes: E[x^2] - E[x]^2 in fp32
+// loses the variance of a channel whose mean dominates it).
+__global__ void bn_partial_var_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
+                                      const float *__restrict__ psum, float inv_m, float *__restrict__ psq) {
+    __shared__ float red[4];
+    const int cq = blockIdx.y, p = blockIdx.x;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < parts; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mean[j] += psum[(size_t)k * 4 * Q + 4 * cq + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mean[j] *= inv_m;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = p; row < rows; row += parts) {
+        const float4 *src = x + ((size_t)row * Q + cq) * W;
+        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
+            const float4 v = src[i];
+            const float a = v.x - mean[0], b = v.y - mean[1], c = v.z - mean[2], d = v.w - mean[3];
+            s.x += a * a, s.y += b * b, s.z += c * c, s.w += d * d;
+        }
+    }
+    const float a = block_sum(s.x, red), b = block_sum(s.y, red), c = block_sum(s.z, red), d = block_sum(s.w, red);
+    if (threadIdx.x == 0) {
+        float *o = psq + (size_t)p * 4 * Q + 4 * cq;
+        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
+    }
+}
+
+// One thread per channel: batch mean / 1/sqrt(var + eps) for the apply pass, and the running buffers as
+// nn.BatchNorm2d keeps them (momentum update with the unbiased variance, batch counter).
+__global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int parts, int C, float m,
+                                   float eps, float momentum, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var, long long *__restrict__ num_batches,
+                                   float *__restrict__ save_mean, float *__restrict__ save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < parts; ++k) s += psum[(size_t)k * C + c], q += psq[(size_t)k * C + c];
+    const float mean = s / m, var = q / m;
+    save_mean[c] = mean;
+    save_rstd[c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m > 1.f ? q / (m - 1.f) : var);
+}
+
+// eval mode: the statistics are the running buffers
+__global__ void bn_eval_stats_kernel(const float *__restrict__ running_mean, const float *__restrict__ running_var, int C,
+                                     float eps, float *__restrict__ save_mean, float *__restrict__ save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save_mean[c] = running_mean[c];
+    save_rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = lrelu(gamma * (x - mean) * rstd + beta), fp32 trunk in, blocked bf16 out.  One thread per (row, unit, pixel):
+// the two fp32 quads of an 8-channel unit in, 16 bytes out.
+__global__ void bn_lrelu_apply_kernel(const float4 *__restrict__ x, size_t n_items, int U, int W,
+                                      const float *__restrict__ mean, const float *__restrict__ rstd,
+                                      const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+                                      __bf16 *__restrict__ out, int out_units, int out_unit_off) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_items; i += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W);
+        const size_t t = i / W;
+        const int u = (int)(t % U);
+        const size_t row = t / U;
+        __bf16 v[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 xv = x[(row * (2 * U) + 2 * u + q) * W + px];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 8 * u + 4 * q + j;
+                const float z = gamma[c] * ((xs[j] - mean[c]) * rstd[c]) + beta[c];
+                v[4 * q + j] = (__bf16)(z > 0.f ? z : z * slope);
+            }
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(out)[(row * out_units + out_unit_off + u) * W + px] = pk;
+    }
+}
+
+// Backward, pass 1: g = dy * lrelu'(z); per-workgroup sums of g and g * xhat for the four channels of a quad.
+__global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const __bf16 *__restrict__ dy, int dy_units,
+                                      int dy_unit_off, int rows, int Q, int W, int parts, const float *__restrict__ mean,
+                                      const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, float slope, float *__restrict__ pg,
+                                      float *__restrict__ pgx) {
+    __shared__ float red[4];
+    const int cq = blockIdx.y, p = blockIdx.x;
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mu[j] = mean[4 * cq + j], rs[j] = rstd[4 * cq + j], ga[j] = gamma[4 * cq + j], be[j] = beta[4 * cq + j];
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int row = p; row < rows; row += parts) {
+        const float4 *src = x + ((size_t)row * Q + cq) * W;
+        const __bf16 *gsrc = dy + (((size_t)row * dy_units + dy_unit_off + (cq >> 1)) * W) * 8 + (cq & 1) * 4;
+        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
+            const float4 xv = src[i];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            uint2 raw = *reinterpret_cast<const uint2 *>(gsrc + (size_t)i * 8);
+            __bf16 gv[4];
+            __builtin_memcpy(gv, &raw, 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xs[j] - mu[j]) * rs[j];
+                const float z = ga[j] * xh + be[j];
+                const float g = (float)gv[j] * (z > 0.f ? 1.f : slope);
+                sg[j] += g, sx[j] += g * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = block_sum(sg[j], red), b = block_sum(sx[j], red);
+        if (threadIdx.x == 0) pg[(size_t)p * 4 * Q + 4 * cq + j] = a, pgx[(size_t)p * 4 * Q + 4 * cq + j] = b;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ pg, const float *__restrict__ pgx, int parts, int C,
+                                       float *__restrict__ dbeta, float *__restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < parts; ++k) s += pg[(size_t)k * C + c], q += pgx[(size_t)k * C + c];
+    dbeta[c] = s;
+    dgamma[c] = q;
+}
+
+// Backward, pass 2: dx = gamma * rstd * (g - dbeta / m - xhat * dgamma / m) in training mode (the batch statistics
+// depend on x), gamma * rstd * g in eval mode; blocked bf16 out, the layout the conv's gradients read.
+__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const __bf16 *__restrict__ dy, int dy_units,
+                                    int dy_unit_off, size_t n_items, int U, int W, const float *__restrict__ mean,
+                                    const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, const float *__restrict__ dbeta,
+                                    const float *__restrict__ dgamma, float inv_m, float slope, int training,
+                                    __bf16 *__restrict__ dx, int dx_units, int dx_unit_off) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_items; i += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % W);
+        const size_t t = i / W;
+        const int u = (int)(t % U);
+        const size_t row = t / U;
+        uint4 graw = reinterpret_cast<const uint4 *>(dy)[(row * dy_units + dy_unit_off + u) * W + px];
+        __bf16 gv[8], v[8];
+        __builtin_memcpy(gv, &graw, 16);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 xv = x[(row * (2 * U) + 2 * u + q) * W + px];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 8 * u + 4 * q + j;
+                const float xh = (xs[j] - mean[c]) * rstd[c];
+                const float z = gamma[c] * xh + beta[c];
+                float g = (float)gv[4 * q + j] * (z > 0.f ? 1.f : slope);
+                if (training) g = g - dbeta[c] * inv_m - xh * dgamma[c] * inv_m;
+                v[4 * q + j] = (__bf16)(gamma[c] * rstd[c] * g);
+            }
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, v, 16);
+        reinterpret_cast<uint4 *>(dx)[(row * dx_units + dx_unit_off + u) * W + px] = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2x2 / stride 2 max pooling on blocked bf16 [N][H][U][W][8] -> [N][H/2][U][W/2][8] (odd trailing row / column dropped).
+__global__ void maxpool2x2_fwd_kernel(const uint4 *__restrict__ in, int H, int W, int U, size_t n_out,
+                                      uint4 *__restrict__ out) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        size_t t = i / Wo;
+        const int u = (int)(t % U);
+        t /= U;
+        const int y = (int)(t % Ho);
+        const size_t n = t / Ho;
+        __bf16 w[4][8], m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 raw = in[((n * H + 2 * y + (k >> 1)) * U + u) * W + 2 * x + (k & 1)];
+            __builtin_memcpy(w[k], &raw, 16);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float best = (float)w[0][e];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) best = (float)w[k][e] > best ? (float)w[k][e] : best;
+            m[e] = (__bf16)best;
+        }
+        uint4 pk;
+        __builtin_memcpy(&pk, m, 16);
+        out[i] = pk;
+    }
+}
+
+// dx of the same pooling: dy goes to the first maximum of its window (row-major order), zeros elsewhere and on an odd
+// trailing row / column.  One thread per INPUT item, so every byte of dx is written.
+__global__ void maxpool2x2_bwd_kernel(const uint4 *__restrict__ in, const uint4 *__restrict__ dy, int H, int W, int U,
+                                      size_t n_in, uint4 *__restrict__ dx) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_in; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t t = i / W;
+        const int u = (int)(t % U);
+        t /= U;
+        const int y = (int)(t % H);
+        const size_t n = t / H;
+        uint4 pk = make_uint4(0, 0, 0, 0);
+        const int yo = y >> 1, xo = x >> 1;
+        if (yo < Ho && xo < Wo) {
+            __bf16 w[4][8], g[8], r[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 raw = in[((n * H + 2 * yo + (k >> 1)) * U + u) * W + 2 * xo + (k & 1)];
+                __builtin_memcpy(w[k], &raw, 16);
+            }
+            const uint4 graw = dy[((n * Ho + yo) * U + u) * Wo + xo];
+            __builtin_memcpy(g, &graw, 16);
+            const int me = (y & 1) * 2 + (x & 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int arg = 0;
+                float best = (float)w[0][e];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if ((float)w[k][e] > best) best = (float)w[k][e], arg = k;
+                r[e] = arg == me ? g[e] : (__bf16)0.f;
+            }
+            __builtin_memcpy(&pk, r, 16);
+        }
+        dx[i] = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mean |a - b| (mode 0) or mean (a - b)^2 (mode 1); b == null: the constant b_const.  grad (optional) receives
+// d(loss)/da = sign(a - b) / n  or  2 (a - b) / n.
+__global__ void loss_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, float b_const, size_t n,
+                                    int mode, float inv_n, float *__restrict__ grad, float *__restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 av = reinterpret_cast<const float4 *>(a)[i];
+        const float4 bv = b ? reinterpret_cast<const float4 *>(b)[i] : make_float4(b_const, b_const, b_const, b_const);
+        const float d[4] = {av.x - bv.x, av.y - bv.y, av.z - bv.z, av.w - bv.w};
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (mode == 0) {
+                s += fabsf(d[j]);
+                g[j] = d[j] > 0.f ? inv_n : (d[j] < 0.f ? -inv_n : 0.f);
+            } else {
+                s += d[j] * d[j];
+                g[j] = 2.f * d[j] * inv_n;
+            }
+        }
+        if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    if (blockIdx.x == 0) {   // tail of a length that is not a multiple of 4
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+            const float d = a[i] - (b ? b[i] : b_const);
+            if (mode == 0) {
+                s += fabsf(d);
+                if (grad) grad[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+            } else {
+                s += d * d;
+                if (grad) grad[i] = 2.f * d * inv_n;
+            }
+        }
+    }
+    const float tot = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void loss_finalize_kernel(const float *__restrict__ partial, int parts, float inv_n, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < parts; i += blockDim.x) s += partial[i];
+    const float tot = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = tot * inv_n;
+}
+
+unsigned aux_grid(size_t items) {
+    size_t b = (items + AUX_THREADS - 1) / AUX_THREADS;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+int bn_parts(int rows) { return rows < BN_MAX_PARTS ? rows : BN_MAX_PARTS; }
+}  // namespace
+
+size_t bn_workspace_floats(int N, int H, int W, int C) {
+    (void)W;
+    return (size_t)2 * bn_parts(N * H) * C;
+}
+
+int launch_bn_lrelu_fwd(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, float eps,
+                        float slope, int training, float momentum, float *running_mean, float *running_var,
+                        long long *num_batches, float *save_mean, float *save_rstd, void *out_act, int out_units,
+                        int out_unit_off, float *workspace, hipStream_t stream) {
+    const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
+    const float m = (float)((double)N * H * W);
+    if (training) {
+        float *psum = workspace, *psq = workspace + (size_t)parts * C;
+        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows, Q,
+                           W, parts, psum);
+        hipLaunchKernelGGL(bn_partial_var_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows, Q,
+                           W, parts, psum, 1.0f / m, psq);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, psum, psq, parts, C, m, eps,
+                           momentum, running_mean, running_var, num_batches, save_mean, save_rstd);
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var, C,
+                           eps, save_mean, save_rstd);
+    }
+    const size_t n_items = (size_t)rows * U * W;
+    hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
+                       n_items, U, W, save_mean, save_rstd, gamma, beta, slope, (__bf16 *)out_act, out_units, out_unit_off);
+    return check_hip(hipGetLastError(), "bn_lrelu_fwd launch");
+}
+
+int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_unit_off, int N, int H, int W, int C,
+                        const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
+                        float slope, int training, void *dx, int dx_units, int dx_unit_off, float *dgamma, float *dbeta,
+                        float *workspace, hipStream_t stream) {
+    const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
+    const float m = (float)((double)N * H * W);
+    float *pg = workspace, *pgx = workspace + (size_t)parts * C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
+                       (const __bf16 *)dy, dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope,
+                       pg, pgx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pg, pgx, parts, C, dbeta,
+                       dgamma);
+    const size_t n_items = (size_t)rows * U * W;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
+                       (const __bf16 *)dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta, dbeta,
+                       dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
+    return check_hip(hipGetLastError(), "bn_lrelu_bwd launch");
+}
+
+int launch_maxpool2x2_fwd(const void *in, int N, int H, int W, int U, void *out, hipStream_t stream) {
+    const size_t n_out = (size_t)N * (H >> 1) * U * (W >> 1);
+    if (n_out == 0) return SR355_OK;
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(aux_grid(n_out)), dim3(AUX_THREADS), 0, stream, (const uint4 *)in, H, W,
+                       U, n_out, (uint4 *)out);
+    return check_hip(hipGetLastError(), "maxpool2x2_fwd launch");
+}
+
+int launch_maxpool2x2_bwd(const void *in, const void *dy, int N, int H, int W, int U, void *dx, hipStream_t stream) {
+    const size_t n_in = (size_t)N * H * U * W;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(aux_grid(n_in)), dim3(AUX_THREADS), 0, stream, (const uint4 *)in,
+                       (const uint4 *)dy, H, W, U, n_in, (uint4 *)dx);
+    return check_hip(hipGetLastError(), "maxpool2x2_bwd launch");
+}
+
+int loss_parts(size_t n) {
+    const size_t b = (n / 4 + AUX_THREADS - 1) / AUX_THREADS;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+int launch_loss(const float *a, const float *b, float b_const, size_t n, int mode, float *loss, float *grad,
+                float *workspace, hipStream_t stream) {
+    const int parts = loss_parts(n);
+    const float inv_n = (float)(1.0 / (double)n);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(parts), dim3(AUX_THREADS), 0, stream, a, b, b_const, n, mode, inv_n, grad,
+                       workspace);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(AUX_THREADS), 0, stream, workspace, parts, inv_n, loss);
+    return check_hip(hipGetLastError(), "loss launch");
+}
+
+}  // namespace sr355

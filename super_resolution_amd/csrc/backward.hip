@@ -151,6 +151,8 @@ struct WgradArgs {
     int N, H, W;               // output-resolution dims
     int in_units, ups;         // input geometry (ups: input at half resolution, nearest x2)
     int dy_units, dy_unit_off;
+    int dy_s2;                 // dy is stored at (H+1)/2 x (W+1)/2 and read as its zero-inserted x2 image: the weight
+                               // gradient of a stride-2 conv whose input has H x W pixels
     int tiles_x, tiles_y;
     // batched launch (blockIdx.z = conv of a dense block sharing `in` and `dy`): per-conv channel chunks,
     // workgroups per chunk, position of its gradient in dy and of its slabs; n_batch = 0: single conv
@@ -204,9 +206,9 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     struct {
         const unsigned char *in, *dy;
         float *slabs, *bias_slabs;
-        int N, H, W, in_units, ups, dy_units, dy_unit_off, tiles_x, tiles_y;
+        int N, H, W, in_units, ups, dy_units, dy_unit_off, tiles_x, tiles_y, dy_s2;
     } a = {a0.in, a0.dy, a0.slabs, a0.bias_slabs, a0.N, a0.H, a0.W, a0.in_units, a0.ups, a0.dy_units, a0.dy_unit_off,
-           a0.tiles_x, a0.tiles_y};
+           a0.tiles_x, a0.tiles_y, a0.dy_s2};
     int nwg = gridDim.x;
     int co_off = 0, co_stride = G::CO;
     if (a0.n_batch > 0) {
@@ -222,7 +224,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     const int H = a.H, W = a.W;
     const int Win = W >> a.ups;
     const int in_img_bytes = (H >> a.ups) * a.in_units * Win * 16;
-    const int dy_img_bytes = H * a.dy_units * W * 16;
+    const int Wd = (W + a.dy_s2) >> a.dy_s2;
+    const int dy_img_bytes = ((H + a.dy_s2) >> a.dy_s2) * a.dy_units * Wd * 16;
     const int n_tiles = a.N * a.tiles_y * a.tiles_x;
 
     int voff[G::KMAX];
@@ -246,7 +249,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
                 const int u = i / WPX;                                                                  \
                 const int p = i - u * WPX;                                                              \
                 const int y = tyi * WTH + (p >> 5), x = txi * 32 + (p & 31);                            \
-                if (y < H && x < W) voff[k] = ((y * a.dy_units + a.dy_unit_off + u) * W + x) * 16;      \
+                if (y < H && x < W && !(a.dy_s2 && ((y | x) & 1)))                                      \
+                    voff[k] = (((y >> a.dy_s2) * a.dy_units + a.dy_unit_off + u) * Wd + (x >> a.dy_s2)) * 16; \
             } else if (j < G::JTOT) {                                                                   \
                 const int i = (j - G::DY_I) * 64 + lane; /* [u][ty][tx] haloed */                       \
                 const int u = i / WIPX;                                                                 \
@@ -602,7 +606,7 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
 
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
-                    hipStream_t stream) {
+                    hipStream_t stream, int dy_stride2) {
     const int co_pad = cout_pad_for(cout);
     if (co_pad != 32 && co_pad != 64) {
         set_error("wgrad3x3: cout=%d not supported (needs <= 64 output channels)", cout);
@@ -619,6 +623,7 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     a.N = N, a.H = H, a.W = W;
     a.in_units = in_units, a.ups = ups;
     a.dy_units = dy_units, a.dy_unit_off = dy_unit_off;
+    a.dy_s2 = dy_stride2 ? 1 : 0;
     a.tiles_x = (W + 31) / 32;
     a.tiles_y = (H + WTH - 1) / WTH;
     static bool attr_done[2][64] = {};

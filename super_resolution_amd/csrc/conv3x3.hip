@@ -59,10 +59,15 @@ __device__ __forceinline__ void mma(f32x16 &c, const f32x4 &a, const f32x4 &b) {
 
 constexpr int TWP = 34;  // tile width 32 + 1 halo pixel each side
 
-template <typename T, int MB, int NB, int SU>
+// ST = 2: stride-2 convolution (nn.Conv2d(c, c, 3, 2, 1) of the discriminator,
+// /root/reference/esrgan/models/esrgan_model.py:67-84): the input tile of a TH x 32 output tile is (2 TH + 1) x 65
+// pixels (pitch 66) and output pixel r of a row reads input pixels 2 r + kx (16-byte slots 32 bytes apart: two-way bank
+// conflicts on the fragment reads, no wasted MFMA).
+template <typename T, int MB, int NB, int SU, int ST = 1>
 struct Geo {
     static constexpr int TH = 4 * NB;
-    static constexpr int NPIX = (TH + 2) * TWP;
+    static constexpr int PITCH = ST == 1 ? TWP : 66;
+    static constexpr int NPIX = (ST * TH + (ST == 1 ? 2 : 1)) * PITCH;
     static constexpr int CO = MB * 32;
     static constexpr int NIN = SU * NPIX;          // 16-byte items of the input image per stage
     static constexpr int KIN = (NIN + 255) / 256;
@@ -73,9 +78,9 @@ struct Geo {
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
 };
 
-template <typename T, int MB, int NB, int SU>
+template <typename T, int MB, int NB, int SU, int ST = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
-    typedef Geo<T, MB, NB, SU> G;
+    typedef Geo<T, MB, NB, SU, ST> G;
     typedef typename Frag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
     const int cb = blockIdx.y;  // block of CO output channels
 
     const int H = a.H, W = a.W;
-    const int Hin = H >> a.ups, Win = W >> a.ups;
+    const int Hin = ST == 2 ? a.in_H : (H + a.zins) >> a.ups, Win = ST == 2 ? a.in_W : (W + a.zins) >> a.ups;
     const unsigned char *in_img = a.in + (size_t)n * Hin * a.in_units * Win * 16;
     const int in_stage_stride = SU * Win * 16;
     const unsigned char *w_base = a.w + (size_t)cb * G::CO * 16;
@@ -112,11 +117,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
         const int i = tid + k * 256;
         const int u = i / G::NPIX;
         const int p = i - u * G::NPIX;
-        const int ty = p / TWP;
-        const int tx = p - ty * TWP;
-        const int y = y0 - 1 + ty, x = x0 - 1 + tx;
-        const bool valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);
-        goff[k] = (valid && !(a.debug & 1)) ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : -1;
+        const int ty = p / G::PITCH;
+        const int tx = p - ty * G::PITCH;
+        const int y = ST * y0 - 1 + ty, x = ST * x0 - 1 + tx;
+        bool valid;
+        if constexpr (ST == 2)
+            valid = (i < G::NIN) && ((unsigned)y < (unsigned)Hin) && ((unsigned)x < (unsigned)Win);
+        else
+            valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W) &&
+                    !(a.zins && ((y | x) & 1));
+        goff[k] = (valid && !SR355_DBG(a, 1)) ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : -1;
     }
     int woff[G::KW];
 #pragma unroll
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
         const int rem = j - u * 9 * G::CO;
         const int tap = rem / G::CO;
         const int co = rem - tap * G::CO;
-        woff[k] = (j < G::NWT && !(a.debug & 1)) ? ((u * 9 + tap) * a.cout_pad + co) * 16 : 0;
+        woff[k] = (j < G::NWT && !SR355_DBG(a, 1)) ? ((u * 9 + tap) * a.cout_pad + co) * 16 : 0;
     }
 
     u32x4 sin[G::KIN], sw[G::KW];
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
 
     const int n_real = a.n_real_stages;
-    const int lane_in = (h * G::NPIX + wave * NB * TWP + r) * 16;
+    const int lane_in = (h * G::NPIX + ST * wave * NB * G::PITCH + ST * r) * 16;
     const int lane_w = G::IN_BYTES + (h * 9 * G::CO + r) * 16;
 
     SR355_STAGE_LOAD(0);
@@ -191,18 +201,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
                     for (int mb = 0; mb < MB; ++mb)
                         wf[ky][mb] = *reinterpret_cast<const frag_t *>(
                             pw + ((2 * s2 * 9 + ky * 3 + kx) * G::CO + mb * 32) * 16);
+                if constexpr (ST == 1) {
 #pragma unroll
-                for (int rho = 0; rho < NB + 2; ++rho) {
-                    const frag_t xf = *reinterpret_cast<const frag_t *>(
-                        pin + (2 * s2 * G::NPIX + rho * TWP + kx) * 16);
+                    for (int rho = 0; rho < NB + 2; ++rho) {
+                        const frag_t xf = *reinterpret_cast<const frag_t *>(
+                            pin + (2 * s2 * G::NPIX + rho * TWP + kx) * 16);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int nb = rho - ky;
-                        if (nb >= 0 && nb < NB) {
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int nb = rho - ky;
+                            if (nb >= 0 && nb < NB) {
+#pragma unroll
+                                for (int mb = 0; mb < MB; ++mb) mma(acc[mb][nb], wf[ky][mb], xf);
+                            }
+                        }
+                    }
+                } else {   // stride 2: output row nb reads input rows 2 nb + ky, nothing shared between taps
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const frag_t xf = *reinterpret_cast<const frag_t *>(
+                                pin + (2 * s2 * G::NPIX + (2 * nb + ky) * G::PITCH + kx) * 16);
 #pragma unroll
                             for (int mb = 0; mb < MB; ++mb) mma(acc[mb][nb], wf[ky][mb], xf);
                         }
-                    }
                 }
             }
         }
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
 
     // ---- epilogue: bias, LeakyReLU, mask, scaled skips, stores ----
     const int x = x0 + r;
-    if (x >= W || (a.debug & 2)) return;
+    if (x >= W || SR355_DBG(a, 2)) return;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int y = y0 + wave * NB + nb;
@@ -234,13 +256,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename T, int MB, int NB, int SU>
+template <typename T, int MB, int NB, int SU, int ST = 1>
 static int launch_inst(const ConvArgs &a0, hipStream_t stream) {
-    typedef Geo<T, MB, NB, SU> G;
+    typedef Geo<T, MB, NB, SU, ST> G;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
-    auto kern = conv3x3_mfma<T, MB, NB, SU>;
+    auto kern = conv3x3_mfma<T, MB, NB, SU, ST>;
     static bool attr_done[64] = {};
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
@@ -300,8 +322,15 @@ int launch_conv3x3(const ConvArgs &a, int dtype, int cin_units, int weight_split
     }
     b.n_real_stages = cin_units / 2;
     b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
-    static const int dbg = [] { const char *e = getenv("SR355_DEBUG"); return e ? atoi(e) : 0; }();
-    b.debug = dbg;
+    b.debug = 0;
+    if (a.stride == 2) {
+        // stride 2 (bf16, unsplit): the register-staged kernel on 4-row output tiles, 64 or 32 outputs per workgroup
+        if (dtype != SR355_DTYPE_BF16 || weight_split || a.ups || a.f16_in) {
+            set_error("conv3x3: stride 2 runs on plain bf16 inputs only");
+            return SR355_ERR_UNSUPPORTED;
+        }
+        return (a.cout_pad % 64) == 0 ? launch_inst<__bf16, 2, 1, 2, 2>(b, stream) : launch_inst<__bf16, 1, 1, 2, 2>(b, stream);
+    }
     if (dtype == SR355_DTYPE_BF16 && (a.cout_pad == 32 || a.cout_pad == 64)) {
         // Large images go to the persistent LDS-DMA ring kernel (one workgroup per CU needs at least
         // a CU's worth of 16x32 tiles); SR355_RING=0/1 forces the choice for A/B measurements.

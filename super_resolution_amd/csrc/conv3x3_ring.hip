@@ -74,8 +74,8 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
     const int r = lane & 31, h = lane >> 5;
 
     const int H = a.H, W = a.W;
-    const int Win = W >> a.ups;
-    const int img_bytes = (H >> a.ups) * a.in_units * Win * 16;
+    const int Win = (W + a.zins) >> a.ups;   // (zins: the zero-inserted x2 image of an (H+1)/2 x (W+1)/2 input)
+    const int img_bytes = ((H + a.zins) >> a.ups) * a.in_units * Win * 16;
     const int in_stage_stride = RSU * Win * 16;
     const int w_stage_stride = RSU * 9 * a.cout_pad * 16;
     const int S = a.n_stages, n_real = a.n_real_stages;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
                 const int tx = p - ty * TWP;                                                          \
                 const int y = tyi_ * G::TH - 1 + ty, x = txi_ * 32 - 1 + tx;                          \
                 const bool valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W) && \
-                                   !(a.debug & 1);                                                    \
+                                   !SR355_DBG(a, 1) && !(a.zins && ((y | x) & 1));                   \
                 voff[k] = valid ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : OOB;  \
             }                                                                                         \
         }                                                                                             \
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void conv3x3_ring(const ConvArgs a
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int y = ty_i * G::TH + wave * NB + nb;
-                const bool ok = (x < W) && (y < H) && !(a.debug & 2);
+                const bool ok = (x < W) && (y < H) && !SR355_DBG(a, 2);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -325,7 +325,11 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
     ConvArgs b = a;
     b.n_real_stages = cin_units / 2;
     b.n_stages = weight_split ? 2 * b.n_real_stages : b.n_real_stages;
+#ifdef SR355_TRACE
     static const int dbg = [] { const char *e = getenv("SR355_DEBUG"); return e ? atoi(e) : 0; }();
+#else
+    const int dbg = 0;
+#endif
     static const int var = [] { const char *e = getenv("SR355_VARIANT"); return e ? atoi(e) : 9; }();
     b.debug = dbg;
     b.trace = g_conv_trace;

@@ -35,7 +35,7 @@ namespace sr355 {
         a.trace[blockIdx.x * 32 + (K)] = __builtin_readcyclecounter();                                        \
         a.trace[blockIdx.x * 32 + 16 + (K)] = wall_clock64();                                                 \
     }
-#define DB_DEBUG(BIT) (a.debug & (BIT))
+#define DB_DEBUG(BIT) (a.debug & (BIT))   // (tools/bench_dense only)
 #else
 #define DB_STAMP(K)
 #define DB_DEBUG(BIT) false

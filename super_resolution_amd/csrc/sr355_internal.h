@@ -36,6 +36,10 @@ struct ConvArgs {
     int n_stages;                // stages to run (2 * n_real_stages with split weights)
     int n_real_stages;           // cin_units / SU: stages of real input
     int ups;                     // 0 | 1
+    int zins;                    // with ups = 1: the input is the zero-inserted x2 image (value at even y, x only, zeros
+                                 // elsewhere; input dims (H+1)/2 x (W+1)/2): the data gradient of a stride-2 conv
+    int stride;                  // 1 | 2 (register-staged kernel only); stride 2 reads an in_H x in_W input
+    int in_H, in_W;
     int out_units, out_unit_off; // geometry of out_act
     int cout_real, cout_pad;
     int f32_units;               // units per pixel of the fp32 trunk tensors (cout_real / 4)
@@ -63,6 +67,14 @@ struct DenseArgs {
     unsigned long long *trace;     // timing experiments only: 8 shader-clock + 8 wall-clock stamps per workgroup
     ConvArgs tail;                 // conv5's epilogue: residuals, carriers, outputs (cout 64); N/H/W set by the launcher
 };
+
+// Timing experiments (skip the loads / the stores of a conv) exist in builds with SR355_TRACE only (csrc/tools); the
+// library proper has no such switch.
+#ifdef SR355_TRACE
+#define SR355_DBG(A, BIT) ((A).debug & (BIT))
+#else
+#define SR355_DBG(A, BIT) false
+#endif
 
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
@@ -124,10 +136,26 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
                           float *const dw[5], float *const db[5], float *slabs, hipStream_t stream);
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
-                    hipStream_t stream);
+                    hipStream_t stream, int dy_stride2 = 0);
 
 // Device address, on the current device, of the library's static scratch array (SR355_STATIC_SCRATCH_BYTES).
 int wgrad_static_scratch(float **out);
+
+// ---- aux_layers.hip ----
+size_t bn_workspace_floats(int N, int H, int W, int C);
+int launch_bn_lrelu_fwd(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, float eps,
+                        float slope, int training, float momentum, float *running_mean, float *running_var,
+                        long long *num_batches, float *save_mean, float *save_rstd, void *out_act, int out_units,
+                        int out_unit_off, float *workspace, hipStream_t stream);
+int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_unit_off, int N, int H, int W, int C,
+                        const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
+                        float slope, int training, void *dx, int dx_units, int dx_unit_off, float *dgamma, float *dbeta,
+                        float *workspace, hipStream_t stream);
+int launch_maxpool2x2_fwd(const void *in, int N, int H, int W, int U, void *out, hipStream_t stream);
+int launch_maxpool2x2_bwd(const void *in, const void *dy, int N, int H, int W, int U, void *dx, hipStream_t stream);
+int loss_parts(size_t n);
+int launch_loss(const float *a, const float *b, float b_const, size_t n, int mode, float *loss, float *grad,
+                float *workspace, hipStream_t stream);
 
 inline int unit_channels(int dtype) { return dtype == SR355_DTYPE_BF16 ? 8 : dtype == SR355_DTYPE_F32 ? 4 : -1; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -4,10 +4,11 @@ Drop-in for ``CVAE`` of /root/reference/condtional VAE/model.py:53-215: same con
 ``state_dict`` keys (``enc_conv{1..4}``, ``fc_mu``, ``fc_logvar``, ``decoder_input``, ``condition_processor``,
 ``dec_conv{1..3}``, ``upsample{1,2}``, ``final_conv``, ``lr_upsampler``), the same ``encode`` / ``reparameterize`` /
 ``decode`` / ``forward`` / ``sample`` methods, trainable through autograd.  Its eight 3x3 convolutions that produce
-something — the encoder (stride 2 taken as the stride-1 result at even positions), the two sub-pixel stages, the final
-conv and the conv behind the bicubic up-sampler — run on the HIP kernels of ``conv_core`` (bf16 operands, fp32
-accumulation; fp32 conv output into every BatchNorm).  The 4x4 transposed convolutions, the linear layers, BatchNorm,
-PixelShuffle, bicubic interpolation and tanh stay on stock PyTorch-ROCm.  ``condition_processor`` keeps its
+something — the encoder (its stride-2 convs computed at the output positions, each with its BatchNorm + LeakyReLU as
+``conv_core.conv_bn_act``), the two sub-pixel stages, the final conv and the conv behind the bicubic up-sampler — run
+on the HIP kernels of ``conv_core`` (bf16 operands, fp32 accumulation; fp32 conv output into every BatchNorm).  The 4x4
+transposed convolutions, the linear layers, the decoder's BatchNorms, PixelShuffle, bicubic interpolation and tanh stay
+on stock PyTorch-ROCm.  ``condition_processor`` keeps its
 parameters (checkpoints carry them) but is not evaluated: the reference computes its output and never uses it
 (model.py:175).  ``VGGPerceptualLoss`` of the same file needs torchvision's ImageNet weights and is not provided.
 """
@@ -25,13 +26,12 @@ def _need_cuda(x: Tensor) -> None:
 
 
 def _conv_f32(x_nchw: Tensor, conv: nn.Conv2d) -> Tensor:
-    """3x3 / pad 1 conv of an NCHW fp32 tensor on the conv core, NCHW fp32 result (stride 2 = even positions)."""
+    """3x3 / pad 1 conv (stride 1 or 2) of an NCHW fp32 tensor on the conv core, NCHW fp32 result."""
     xb = cc.to_blocked(x_nchw.contiguous())
+    stride = int(conv.stride[0])
     if conv.out_channels % 16:
-        y = cc.conv3x3(xb, conv.weight, conv.bias, 1.0, nchw_out=True)
-    else:
-        y = cc.f32_as_nchw(cc.conv3x3(xb, conv.weight, conv.bias, 1.0, f32_out=True))
-    return y[:, :, ::2, ::2] if conv.stride[0] == 2 else y
+        return cc.conv3x3(xb, conv.weight, conv.bias, 1.0, nchw_out=True, stride=stride)
+    return cc.f32_as_nchw(cc.conv3x3(xb, conv.weight, conv.bias, 1.0, f32_out=True, stride=stride))
 
 
 class CVAE(nn.Module):
@@ -68,9 +68,11 @@ class CVAE(nn.Module):
     def encode(self, x: Tensor):
         _need_cuda(x)
         x1 = F.leaky_relu(_conv_f32(x.float(), self.enc_conv1[0]), 0.2)
-        feats, h = [x1], x1
+        feats, hb, h = [x1], cc.to_blocked(x1.contiguous()), x1
         for block in (self.enc_conv2, self.enc_conv3, self.enc_conv4):
-            h = F.leaky_relu(block[1](_conv_f32(h, block[0])), 0.2)
+            # stride-2 conv -> BatchNorm (batch statistics in training mode) -> LeakyReLU, blocked bf16 throughout
+            hb = cc.conv_bn_act(hb, block[0], block[1], 0.2)
+            h = cc.from_blocked(hb, block[0].out_channels)
             feats.append(h)
         encoded = self.flatten(h)
         return self.fc_mu(encoded), self.fc_logvar(encoded), tuple(feats)

@@ -38,8 +38,8 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, channels: int):
         super().__init__()
-        if channels % 8:
-            raise ValueError("channels must be a multiple of 8 (whole 8-channel units)")
+        if channels % 16:
+            raise ValueError("channels must be a multiple of 16 (the fp32 trunk output runs on 16-channel groups)")
         self.conv1 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(channels, channels, kernel_size=3, padding=1)
@@ -64,8 +64,8 @@ class GeneratorSR(nn.Module):
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, num_residual: int = 6, base_channels: int = 64):
         super().__init__()
-        if base_channels % 8:
-            raise ValueError("base_channels must be a multiple of 8 (whole 8-channel units)")
+        if base_channels % 16:
+            raise ValueError("base_channels must be a multiple of 16 (the fp32 trunk output runs on 16-channel groups)")
         self.conv1 = nn.Sequential(nn.Conv2d(in_channels, base_channels, kernel_size=7, stride=1, padding=3),
                                    nn.ReLU(inplace=True))
         self.res_blocks = nn.Sequential(*[ResidualBlock(base_channels) for _ in range(num_residual)])

@@ -3,8 +3,10 @@
 Drop-ins for /root/reference/esrgan/models/esrgan_model.py:64-103: same class names, constructor
 arguments and ``state_dict`` keys (the parameters live in the same ``nn.Sequential`` containers), so
 checkpoints interchange.  Every 3x3 convolution runs through ``conv_core.conv3x3`` (the generator's MFMA
-kernels, forward / data gradient / weight gradient); BatchNorm, max pooling and stride-2 sampling are torch
-ops on views of the blocked bf16 activations, so autograd composes the backward pass.  No CPU path.
+kernels, forward / data gradient / weight gradient; stride 2 computed at the output positions); BatchNorm +
+LeakyReLU and max pooling are HIP kernels on the blocked layout as well (``conv_core.conv_bn_act``,
+``conv_core.max_pool2x2``), forward and backward, and the L1 / MSE terms of the two training iterations are one
+reduction kernel each (``conv_core.l1_loss`` / ``mse_loss``).  No CPU path.
 
 ``pixel_step`` / ``adversarial_step`` restate the two loop bodies of /root/reference/esrgan/train.py
 (:157-164 and :196-223) as functions of the same objects the script holds.
@@ -32,8 +34,8 @@ class Discriminator(nn.Module):
 
     def __init__(self, in_channels: int = 3, base_channels: int = 64):
         super().__init__()
-        if base_channels % 8:
-            raise ValueError("base_channels must be a multiple of 8 (whole 8-channel units)")
+        if base_channels % 16:
+            raise ValueError("base_channels must be a multiple of 16 (the normalised layers run on 16-channel groups)")
 
         def conv_block(in_f, out_f, stride=1, bn=True):
             layers = [nn.Conv2d(in_f, out_f, 3, stride, 1)]
@@ -68,17 +70,13 @@ class Discriminator(nn.Module):
             if isinstance(mods[i], nn.BatchNorm2d):
                 bn, act = mods[i], mods[i + 1]
                 i += 2
-                y = cc.conv3x3(x, conv.weight, conv.bias, 1.0, f32_out=True)    # fp32 into the normalisation
-                if conv.stride[0] == 2:                                  # k=3, s=2, p=1 = the s=1 result at even positions
-                    y = y[:, ::2, :, ::2]
-                v = bn(cc.f32_as_nchw(y))                                # batch statistics / running buffers as nn.BatchNorm2d
-                x = cc.nchw_as_blocked(F.leaky_relu(v, act.negative_slope))
+                # conv (stride 1 or 2, fp32 out) -> batch statistics / running buffers as nn.BatchNorm2d -> LeakyReLU,
+                # blocked bf16 out: three HIP stages, no layout shuffle
+                x = cc.conv_bn_act(x, conv, bn, act.negative_slope)
             else:
                 act = mods[i]
                 i += 1
-                x = cc.conv3x3(x, conv.weight, conv.bias, act.negative_slope)   # LeakyReLU fused into the conv
-                if conv.stride[0] == 2:
-                    x = x[:, ::2, :, ::2].contiguous()
+                x = cc.conv3x3(x, conv.weight, conv.bias, act.negative_slope, stride=conv.stride[0])   # LeakyReLU fused
         raise RuntimeError("unreachable")
 
 
@@ -160,7 +158,7 @@ def pixel_step(netG: nn.Module, optim_G, lr: Tensor, hr: Tensor, scaler=None) ->
     """One iteration of the pixel-loss pre-training loop (train.py:157-163): L1(netG(lr), hr), backward, Adam."""
     optim_G.zero_grad()
     sr = netG(lr)
-    loss_pix = F.l1_loss(sr, hr)
+    loss_pix = cc.l1_loss(sr, hr)
     _backward_and_step(loss_pix, optim_G, scaler)
     return {"loss_pix": loss_pix.detach()}
 
@@ -174,18 +172,17 @@ def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, 
         fake = netG(lr)
     pred_real = netD(hr)
     pred_fake = netD(fake)
-    loss_D = 0.5 * (F.mse_loss(pred_real, torch.ones_like(pred_real)) +
-                    F.mse_loss(pred_fake, torch.zeros_like(pred_fake)))
+    loss_D = 0.5 * (cc.mse_loss(pred_real, 1.0) + cc.mse_loss(pred_fake, 0.0))
     _backward_and_step(loss_D, optim_D, scaler_D)
 
     optim_G.zero_grad()
     fake = netG(lr)
     pred_fake = netD(fake)
-    loss_G_gan = F.mse_loss(pred_fake, torch.ones_like(pred_fake))
-    loss_G_pix = F.l1_loss(fake, hr)
+    loss_G_gan = cc.mse_loss(pred_fake, 1.0)
+    loss_G_pix = cc.l1_loss(fake, hr)
     feat_sr = vgg(fake)
     feat_hr = vgg(hr)
-    loss_G_per = F.l1_loss(feat_sr, feat_hr)
+    loss_G_per = cc.l1_loss(feat_sr, feat_hr)
     loss_G = loss_G_pix + 0.01 * loss_G_per + 1e-3 * loss_G_gan
     _backward_and_step(loss_G, optim_G, scaler_G)
     return {"loss_D": loss_D.detach(), "loss_G": loss_G.detach(), "loss_G_pix": loss_G_pix.detach(),

@@ -21,10 +21,17 @@ _CODE = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}
 UNIT_CHANNELS = {DTYPE_BF16: 8, DTYPE_F32: 4}
 
 
+# torch keeps the raw-handle getters private; where a torch version drops them the public (slower) API takes over
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def _stream() -> C.c_void_p:
     """The current HIP stream of the current device, as the C ABI takes it (the raw handle, without building a
     ``torch.cuda.Stream`` object around it: this runs once per kernel call)."""
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(_CUR_DEVICE()))
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 _SAME_DEVICE = contextlib.nullcontext()
@@ -33,7 +40,7 @@ _SAME_DEVICE = contextlib.nullcontext()
 def _on(device: torch.device):
     """Context in which ``device`` is the current device; nothing to enter when it already is."""
     idx = device.index
-    return _SAME_DEVICE if idx is None or idx == torch._C._cuda_getDevice() else torch.cuda.device(device)
+    return _SAME_DEVICE if idx is None or idx == _CUR_DEVICE() else torch.cuda.device(device)
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
@@ -130,8 +137,11 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
               out_f32: Optional[Tensor], out_nchw: Optional[Tensor], weight_split: int = 0,
               mask: Optional[Tensor] = None, mask_unit_off: int = 0, mask_slope: float = 1.0,
               res1_weight: float = 1.0, res2_weight: float = 1.0, f16_in: bool = False,
-              f16_out: bool = False, res_act: Optional[Tensor] = None) -> ConvArgs:
-    """The sr355_conv_args record for one conv launch (the tensors must outlive its use)."""
+              f16_out: bool = False, res_act: Optional[Tensor] = None, stride: int = 1,
+              zero_insert: bool = False) -> ConvArgs:
+    """The sr355_conv_args record for one conv launch (the tensors must outlive its use).  ``stride=2``: the output
+    tensors have ``(in+1)//2`` rows and columns; ``zero_insert`` (with ``upsample=1``): the input is read as its
+    zero-inserted x2 image, the data gradient of a stride-2 conv."""
     _need_cuda(in_buf, w_packed, bias_packed, res1, res2, out_act, out_f32, out_nchw, mask)
     a = ConvArgs()
     a.dtype = _CODE[in_buf.dtype]
@@ -146,9 +156,19 @@ def conv_args(in_buf: Tensor, cin_units: int, w_packed: Tensor, bias_packed: Ten
     a.N, a.H, a.W, a.upsample = int(N), int(H), int(W), int(upsample)
     a.in_dev, a.in_bytes = in_buf.data_ptr(), _nbytes(in_buf)
     a.in_units, a.cin_units = int(in_buf.shape[2]), int(cin_units)
-    if in_buf.shape[0] != N or in_buf.shape[1] != (H >> upsample) or in_buf.shape[3] != (W >> upsample):
+    if stride == 2:
+        want_h, want_w = int(in_buf.shape[1]), int(in_buf.shape[3])
+        if (want_h + 1) // 2 != H or (want_w + 1) // 2 != W:
+            raise RuntimeError(f"conv3x3_fwd: stride-2 output of a {want_h}x{want_w} input is "
+                               f"{(want_h + 1) // 2}x{(want_w + 1) // 2}, not {H}x{W}")
+        a.stride, a.in_H, a.in_W = 2, want_h, want_w
+    else:
+        z = 1 if zero_insert else 0
+        want_h, want_w = (H + z) >> upsample, (W + z) >> upsample
+        a.zero_insert = z
+    if in_buf.shape[0] != N or in_buf.shape[1] != want_h or in_buf.shape[3] != want_w:
         raise RuntimeError(f"conv3x3_fwd: input {tuple(in_buf.shape)} does not match output N={N} H={H} W={W} "
-                           f"upsample={upsample}")
+                           f"upsample={upsample} stride={stride}")
     a.w_packed_dev, a.w_packed_bytes = w_packed.data_ptr(), _nbytes(w_packed)
     a.weight_split = int(weight_split)
     a.bias_packed_dev = bias_packed.data_ptr()
@@ -313,7 +333,8 @@ def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
     return None
 
 
-def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor) -> None:
+def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor,
+                      stride: int = 1) -> None:
     """Weight / bias gradient of a conv with any number of output channels: ``sr355_conv3x3_wgrad`` takes at most 64
     of them a call, so this walks ``dy`` in 64-channel slices — one argument block, one workspace and one device
     context for all of them (a 512-channel layer is eight calls; built per call they cost more host time than
@@ -324,9 +345,10 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
     if not (dw.is_contiguous() and db.is_contiguous()) or dw.shape[0] != cout or db.numel() != cout:
         raise RuntimeError("conv3x3_wgrad_all: dw [cout, cin, 3, 3] and db [cout] must be contiguous fp32 tensors")
     L = _lib.lib()
-    N, H, _U, W, _c = (int(v) for v in dy.shape)
+    N, H, _U, W, _c = (int(v) for v in (dy.shape if stride == 1 else in_buf.shape))   # stride 2: the input's size
     a = WgradArgs()
     a.N, a.H, a.W, a.upsample = N, H, W, 0
+    a.dy_stride2 = 1 if stride == 2 else 0
     a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
     a.dy_dev, a.dy_bytes, a.dy_units = dy.data_ptr(), _nbytes(dy), int(dy.shape[2])
     a.scale, a.accumulate = 1.0, 0
@@ -343,6 +365,122 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
             a.dy_unit_off, a.cout = c0 // 8, cb
             a.dw_dev, a.dw_bytes, a.db_dev = dw_ptr + c0 * row, cb * row, db_ptr + c0 * 4
             check(L.sr355_conv3x3_wgrad(C.byref(a), stream), "sr355_conv3x3_wgrad")
+
+
+# ------------------------------------------------------------------------------------
+# Layers around the convs of the discriminator / VGG19 and the loss reductions (csrc/aux_layers.hip)
+@torch.library.custom_op("sr355::bn_lrelu_fwd", mutates_args=("running_mean", "running_var", "num_batches_tracked",
+                                                                "save_mean", "save_rstd", "out_act"))
+def bn_lrelu_fwd(x_f32: Tensor, gamma: Tensor, beta: Tensor, eps: float, slope: float, training: bool, momentum: float,
+                 running_mean: Optional[Tensor], running_var: Optional[Tensor], num_batches_tracked: Optional[Tensor],
+                 save_mean: Tensor, save_rstd: Tensor, out_act: Tensor, out_unit_off: int = 0) -> None:
+    """BatchNorm2d (batch statistics when ``training``) + LeakyReLU of an fp32 conv output ``[N, H, C/4, W, 4]`` into
+    blocked bf16 ``out_act``; updates the running buffers like nn.BatchNorm2d."""
+    _need_cuda(x_f32, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, out_act)
+    N, H, Q, W, _c = (int(v) for v in x_f32.shape)
+    L = _lib.lib()
+    need = L.sr355_bn_workspace_bytes(N, H, W, 4 * Q)
+    if need == 0:
+        raise RuntimeError("bn_lrelu_fwd: channels must be a positive multiple of 8")
+    ws = torch.empty(need, dtype=torch.uint8, device=x_f32.device)
+    with _on(x_f32.device):
+        check(L.sr355_bn_lrelu_fwd(x_f32.data_ptr(), _nbytes(x_f32), N, H, W, 4 * Q, gamma.data_ptr(), beta.data_ptr(),
+                                   float(eps), float(slope), int(bool(training)), float(momentum), _ptr(running_mean),
+                                   _ptr(running_var), _ptr(num_batches_tracked), save_mean.data_ptr(),
+                                   save_rstd.data_ptr(), out_act.data_ptr(), _nbytes(out_act), int(out_act.shape[2]),
+                                   int(out_unit_off), ws.data_ptr(), need, _stream()), "sr355_bn_lrelu_fwd")
+
+
+@bn_lrelu_fwd.register_fake
+def _(x_f32, gamma, beta, eps, slope, training, momentum, running_mean, running_var, num_batches_tracked, save_mean,
+      save_rstd, out_act, out_unit_off=0):
+    return None
+
+
+@torch.library.custom_op("sr355::bn_lrelu_bwd", mutates_args=("dx_act", "dgamma", "dbeta"))
+def bn_lrelu_bwd(x_f32: Tensor, dy_act: Tensor, gamma: Tensor, beta: Tensor, save_mean: Tensor, save_rstd: Tensor,
+                 slope: float, training: bool, dx_act: Tensor, dgamma: Tensor, dbeta: Tensor, dy_unit_off: int = 0,
+                 dx_unit_off: int = 0) -> None:
+    """Backward of ``bn_lrelu_fwd``: the gradient of x as blocked bf16, and dgamma / dbeta."""
+    _need_cuda(x_f32, dy_act, gamma, beta, save_mean, save_rstd, dx_act, dgamma, dbeta)
+    N, H, Q, W, _c = (int(v) for v in x_f32.shape)
+    L = _lib.lib()
+    need = L.sr355_bn_workspace_bytes(N, H, W, 4 * Q)
+    ws = torch.empty(need, dtype=torch.uint8, device=x_f32.device)
+    with _on(x_f32.device):
+        check(L.sr355_bn_lrelu_bwd(x_f32.data_ptr(), _nbytes(x_f32), dy_act.data_ptr(), _nbytes(dy_act),
+                                   int(dy_act.shape[2]), int(dy_unit_off), N, H, W, 4 * Q, gamma.data_ptr(),
+                                   beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), float(slope),
+                                   int(bool(training)), dx_act.data_ptr(), _nbytes(dx_act), int(dx_act.shape[2]),
+                                   int(dx_unit_off), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), need, _stream()),
+              "sr355_bn_lrelu_bwd")
+
+
+@bn_lrelu_bwd.register_fake
+def _(x_f32, dy_act, gamma, beta, save_mean, save_rstd, slope, training, dx_act, dgamma, dbeta, dy_unit_off=0,
+      dx_unit_off=0):
+    return None
+
+
+@torch.library.custom_op("sr355::maxpool2x2_fwd", mutates_args=())
+def maxpool2x2_fwd(x: Tensor) -> Tensor:
+    """nn.MaxPool2d(2, 2) on a blocked bf16 tensor ``[N, H, U, W, 8]`` -> ``[N, H//2, U, W//2, 8]``."""
+    _need_cuda(x)
+    if x.dtype != torch.bfloat16 or x.dim() != 5:
+        raise RuntimeError("maxpool2x2 runs on blocked bf16 tensors")
+    N, H, U, W, _c = (int(v) for v in x.shape)
+    out = torch.empty((N, H // 2, U, W // 2, 8), dtype=torch.bfloat16, device=x.device)
+    with _on(x.device):
+        check(_lib.lib().sr355_maxpool2x2_fwd(x.data_ptr(), _nbytes(x), N, H, W, U, out.data_ptr(), _nbytes(out),
+                                              _stream()), "sr355_maxpool2x2_fwd")
+    return out
+
+
+@maxpool2x2_fwd.register_fake
+def _(x):
+    N, H, U, W, c = x.shape
+    return x.new_empty((N, H // 2, U, W // 2, c))
+
+
+@torch.library.custom_op("sr355::maxpool2x2_bwd", mutates_args=())
+def maxpool2x2_bwd(x: Tensor, dy: Tensor) -> Tensor:
+    """Gradient of ``maxpool2x2_fwd`` with respect to its input ``x`` (first maximum of a window takes it all)."""
+    _need_cuda(x, dy)
+    N, H, U, W, _c = (int(v) for v in x.shape)
+    dx = torch.empty_like(x)
+    with _on(x.device):
+        check(_lib.lib().sr355_maxpool2x2_bwd(x.data_ptr(), _nbytes(x), dy.data_ptr(), _nbytes(dy), N, H, W, U,
+                                              dx.data_ptr(), _nbytes(dx), _stream()), "sr355_maxpool2x2_bwd")
+    return dx
+
+
+@maxpool2x2_bwd.register_fake
+def _(x, dy):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("sr355::loss_fwd", mutates_args=())
+def loss_fwd(a: Tensor, b: Optional[Tensor], b_const: float, mode: int, want_grad: bool) -> Tuple[Tensor, Tensor]:
+    """mean |a - b| (mode 0) or mean (a - b)^2 (mode 1) of fp32 tensors (``b`` None: the constant ``b_const``) and, when
+    ``want_grad``, d(loss)/da from the same pass (else an empty tensor)."""
+    _need_cuda(a, b)
+    if a.dtype != torch.float32 or (b is not None and (b.dtype != torch.float32 or b.shape != a.shape)):
+        raise RuntimeError("loss_fwd: fp32 tensors of one shape")
+    L = _lib.lib()
+    n = a.numel()
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else torch.empty(0, dtype=torch.float32, device=a.device)
+    need = L.sr355_loss_workspace_bytes(n)
+    ws = torch.empty(max(need, 4), dtype=torch.uint8, device=a.device)
+    with _on(a.device):
+        check(L.sr355_loss_fwd(a.data_ptr(), _ptr(b), float(b_const), n, int(mode), loss.data_ptr(),
+                               grad.data_ptr() if want_grad else None, ws.data_ptr(), need, _stream()), "sr355_loss_fwd")
+    return loss, grad
+
+
+@loss_fwd.register_fake
+def _(a, b, b_const, mode, want_grad):
+    return a.new_empty(()), (torch.empty_like(a) if want_grad else a.new_empty(0))
 
 
 # ------------------------------------------------------------------------------------
@@ -613,6 +751,11 @@ def now(op):
 
 
 conv3x3_fwd_now = now(conv3x3_fwd)
+bn_lrelu_fwd_now = now(bn_lrelu_fwd)
+bn_lrelu_bwd_now = now(bn_lrelu_bwd)
+maxpool2x2_fwd_now = now(maxpool2x2_fwd)
+maxpool2x2_bwd_now = now(maxpool2x2_bwd)
+loss_fwd_now = now(loss_fwd)
 conv3x3_wgrad_now = now(conv3x3_wgrad)
 to_blocked_now = now(to_blocked)
 from_blocked_now = now(from_blocked)
