@@ -117,18 +117,30 @@ _HR_SIDE = ("upconv1", "upconv2", "HR_conv", "conv_last")
 
 def _conv(sd: StateDict, name: str, x: torch.Tensor, emulate_bf16, stride: int = 1) -> torch.Tensor:
     """``emulate_bf16``: False = fp32 (the reference); True = every conv rounds weights and input to
-    bf16; "hr_split" = as True, except that the HR-side convs keep their weights exact and
-    conv_first keeps weights and input exact (the residue-carrying modes of the HIP path); "hr_f16" = as
+    bf16; "hr_split" = as True, except that the HR-side convs carry their weights, and conv_first its weights and
+    input, as a bf16 value plus the bf16 rounding of the residue (the residue-carrying modes of the HIP path); "hr_f16" = as
     "hr_split", except that the HR-side convs round weights and input to fp16 instead."""
     w, b = sd[name + ".weight"], sd[name + ".bias"]
     if emulate_bf16 == "hr_f16" and name in _HR_SIDE:
         return F.conv2d(x.to(torch.float16).float(), w.to(torch.float16).float(), b, stride=stride, padding=1)
     if emulate_bf16:
         split = emulate_bf16 in ("hr_split", "hr_f16")
-        if not (split and (name in _HR_SIDE or name == "conv_first")):
-            w = _bf16r(w)
-        if not (split and name == "conv_first"):
-            x = _bf16r(x)
+        carried = split and (name in _HR_SIDE or name == "conv_first")
+        if carried:
+            # "exact" on the HIP path means a bf16 value plus the bf16 rounding of its residue (16 significant bits).
+            # The difference from the fp32 value is 2^-17 relative, but this network amplifies it: a perturbed sum
+            # that crosses a bf16 rounding boundary downstream moves that activation by a whole bf16 step.
+            w_hi = _bf16r(w)
+            w_lo = _bf16r(w - w_hi)
+            if name == "conv_first":
+                x_hi = _bf16r(x)
+                x_lo = _bf16r(x - x_hi)
+                # three of the four products; lo * lo (2^-18 of the result) is not computed
+                return F.conv2d(x_hi, w_hi + w_lo, b, stride=stride, padding=1) + \
+                    F.conv2d(x_lo, w_hi, None, stride=stride, padding=1)
+            return F.conv2d(_bf16r(x), w_hi + w_lo, b, stride=stride, padding=1)
+        w = _bf16r(w)
+        x = _bf16r(x)
     return F.conv2d(x, w, b, stride=stride, padding=1)
 
 

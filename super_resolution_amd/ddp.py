@@ -93,19 +93,41 @@ def reduce_in_buckets(flat: Tensor, buckets: Sequence[Tuple[int, int, int, int]]
             view.div_(world)
 
 
+class PendingMean:
+    """An in-place mean over the ranks of a group that has been started and not yet waited for."""
+
+    def __init__(self, t: Tensor, group=None):
+        import torch.distributed as dist
+        self.t, self.world = t, dist.get_world_size(group)
+        self.host = None
+        if dist.get_backend(group) == "nccl":
+            # RCCL runs the collective on its own stream; wait() makes the caller's stream (not the host) wait for it
+            self.handle = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True)
+            self.avg = True
+        else:
+            # gloo (tests, CPU-only fabrics): a device tensor is staged through host memory (gloo's own device-tensor
+            # collectives stall when ranks share a GPU)
+            self.host = t.cpu() if t.is_cuda else t
+            self.handle = dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            self.avg = False
+
+    def wait(self) -> None:
+        self.handle.wait()
+        if not self.avg:
+            self.host.div_(self.world)
+            if self.host is not self.t:
+                self.t.copy_(self.host)
+
+
+def start_all_reduce_mean(t: Tensor, group=None) -> PendingMean:
+    """Start the in-place mean of ``t`` over the ranks of ``group`` and return at once; kernels enqueued before
+    ``wait()`` on the returned object overlap with the collective."""
+    return PendingMean(t, group)
+
+
 def all_reduce_mean(t: Tensor, group=None) -> None:
-    """In-place mean of ``t`` over the ranks of ``group``: one RCCL all-reduce (``backend="nccl"``); on gloo a device
-    tensor is staged through host memory (gloo's own device-tensor collectives stall when ranks share a GPU)."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if dist.get_backend(group) == "nccl":
-        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-        return
-    host = t.cpu() if t.is_cuda else t
-    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-    host.div_(world)
-    if host is not t:
-        t.copy_(host)
+    """In-place mean of ``t`` over the ranks of ``group``: one RCCL all-reduce (``backend="nccl"``)."""
+    PendingMean(t, group).wait()
 
 
 def broadcast_tensors(tensors, src: int = 0, group=None) -> None:
@@ -132,7 +154,8 @@ class DistributedGenerator(nn.Module):
         self.group = group
         m = module
         self.slices = phase_slices(m.in_channels, m.out_channels, m.num_features, m.num_blocks, m.growth_channels)
-        self.buckets = plan_buckets(self.slices, int(bucket_mb * (1 << 20) / 4))
+        # bucket_mb = float("inf"): one all-reduce of the whole buffer after the backward
+        self.buckets = plan_buckets(self.slices, (1 << 62) if bucket_mb == float("inf") else int(bucket_mb * (1 << 20) / 4))
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist

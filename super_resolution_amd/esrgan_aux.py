@@ -166,22 +166,33 @@ def pixel_step(netG: nn.Module, optim_G, lr: Tensor, hr: Tensor, scaler=None) ->
 def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, optim_D, lr: Tensor, hr: Tensor,
                      scaler_G=None, scaler_D=None) -> Dict[str, Tensor]:
     """One iteration of the adversarial loop (train.py:196-223): the discriminator update on (hr, detached fake),
-    then the generator update with loss_G = L1 + 0.01 * L1(vgg) + 1e-3 * MSE(D(fake), 1) on a second forward."""
-    optim_D.zero_grad()
-    with torch.no_grad():
-        fake = netG(lr)
-    pred_real = netD(hr)
-    pred_fake = netD(fake)
-    loss_D = 0.5 * (cc.mse_loss(pred_real, 1.0) + cc.mse_loss(pred_fake, 0.0))
-    _backward_and_step(loss_D, optim_D, scaler_D)
+    then the generator update with loss_G = L1 + 0.01 * L1(vgg) + 1e-3 * MSE(D(fake), 1).
 
+    The reference runs the generator twice on the same batch (:198 for the discriminator's detached fake, :211 for
+    its own loss); its weights do not change in between and it has no stochastic layer, so both calls return the same
+    tensor.  Here it runs once, recorded, and the discriminator update takes the detached result: one generator
+    forward less per iteration, and both updates see a fake image computed with the same arithmetic."""
+    optim_D.zero_grad()
     optim_G.zero_grad()
     fake = netG(lr)
+    pred_real = netD(hr)
+    pred_fake = netD(fake.detach())
+    loss_D = 0.5 * (cc.mse_loss(pred_real, 1.0) + cc.mse_loss(pred_fake, 0.0))
+    begin = getattr(optim_D, "begin_step", None) if scaler_D is None else None
+    if begin is None:
+        _backward_and_step(loss_D, optim_D, scaler_D)
+        feat_sr, feat_hr = vgg(fake), vgg(hr)
+    else:
+        # data parallel: the two VGG19 forwards need neither D's gradients nor its new weights, so they are enqueued
+        # while the all-reduce of D's gradients is in flight
+        loss_D.backward()
+        begin()
+        feat_sr, feat_hr = vgg(fake), vgg(hr)
+        optim_D.step()
+
     pred_fake = netD(fake)
     loss_G_gan = cc.mse_loss(pred_fake, 1.0)
     loss_G_pix = cc.l1_loss(fake, hr)
-    feat_sr = vgg(fake)
-    feat_hr = vgg(hr)
     loss_G_per = cc.l1_loss(feat_sr, feat_hr)
     loss_G = loss_G_pix + 0.01 * loss_G_per + 1e-3 * loss_G_gan
     _backward_and_step(loss_G, optim_G, scaler_G)

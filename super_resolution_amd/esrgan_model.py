@@ -108,10 +108,64 @@ class ResidualDenseBlock(nn.Module):
             ops.conv3x3_fwd(buf, (nf + 4 * gc) // cpu, wp, bp, nf, 1.0, 0, trunk_in, self.res_scale, outer, _RES,
                             nxt, 0, outer_out, None)
 
+    def _packed_bwd(self):
+        """Transposed (data-gradient) packs of the five convs, stacked as the gradient stack
+        [dOut | dY4 | dY3 | dY2 | dY1] reads them; conv5's slices carry the dense skip's scale."""
+        nf, gc = self.in_channels, self.growth_channels
+        weights = [c.weight for c in self._convs()]
+
+        def build():
+            packs = []
+            for j in (4, 3, 2, 1, 0):                      # step producing dY_j (j = 0: the block input's gradient)
+                ci_lo, n_out = (nf + (j - 1) * gc, gc) if j else (0, nf)
+                units = (nf + (4 - j) * gc) // 8
+                wt = torch.zeros(units * 9 * ((n_out + 31) // 32 * 32) * 16, dtype=torch.uint8, device=weights[0].device)
+                ops.pack_weight_transposed(weights[4].detach(), ci_lo, n_out, self.res_scale, wt, units, 0, DTYPE_BF16)
+                for k in range(4, j, -1):
+                    ops.pack_weight_transposed(weights[k - 1].detach(), ci_lo, n_out, 1.0, wt, units,
+                                               (nf + (4 - k) * gc) // 8, DTYPE_BF16)
+                packs.append(wt)
+            return packs
+        return self._cache.get(weights, ("bwd", DTYPE_BF16), build, not _is_replica(self))
+
+    def _backward(self, act: Tensor, g: Tensor, outer_scale: float, grads: List[Tensor]) -> Tensor:
+        """Backward of ``x + res_scale * conv5(...)`` given the saved block buffer ``act`` and ``g``, the gradient
+        (NCHW fp32) of ``outer_scale`` times ... the block output: returns the conv path's share of the input
+        gradient, ``outer_scale * d(conv path)/dx^T g``, and appends (dw, db) of conv1..conv5 to ``grads``."""
+        nf, gc = self.in_channels, self.growth_channels
+        N, H, _u, W, _c = act.shape
+        dev = act.device
+        stack = ops.to_blocked(g, act.shape[2], DTYPE_BF16)            # units [0, nf/8): dOut
+        packs = self._packed_bwd()
+        zero = torch.zeros(64, dtype=torch.float32, device=dev)
+        dxc = torch.empty((N, H, nf // 4, W, 4), dtype=torch.float32, device=dev)
+        mask_off = [(nf + (3 - k) * gc) // 8 for k in range(4)]
+        if W <= ops.DENSE_BLOCK_MAX_WIDTH and nf == 64 and gc == 32:
+            ops.dense_block_fwd(stack, packs, [zero] * 5, 1.0, True, None, 1.0, None, 0.0, None, dxc, mask=act,
+                                mask_unit_off=mask_off, mask_slope=_SLOPE)
+        else:
+            for k in range(4):
+                ops.conv3x3_fwd(stack, (nf + k * gc) // 8, packs[k], zero, gc, 1.0, 0, None, 0.0, None, 0.0, stack,
+                                (nf + k * gc) // 8, None, None, mask=act, mask_unit_off=mask_off[k], mask_slope=_SLOPE)
+            ops.conv3x3_fwd(stack, (nf + 4 * gc) // 8, packs[4], zero, nf, 1.0, 0, None, 0.0, None, 0.0, None, 0, dxc, None)
+        if outer_scale != 1.0:          # the stack was built from the unscaled gradient: everything is linear in it
+            dxc = dxc * outer_scale
+        for k, conv in enumerate(self._convs()):
+            cin, cout = nf + k * gc, (gc if k < 4 else nf)
+            dw = torch.empty_like(conv.weight, dtype=torch.float32)
+            db = torch.empty((cout,), dtype=torch.float32, device=dev)
+            dy_off = (nf + (3 - k) * gc) // 8 if k < 4 else 0
+            ops.conv3x3_wgrad(act, cin, 0, stack, dy_off, cout, outer_scale * (1.0 if k < 4 else self.res_scale), 0, dw, db)
+            grads += [dw, db]
+        return ops.from_blocked(dxc, 0, nf)
+
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
-        _no_grad_only(self, x)
         dtype = _PRECISIONS[self.precision]
+        if _records_graph(self, x):
+            if dtype != DTYPE_BF16:
+                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+            return _BlockFunction.apply(x.float().contiguous(), self, *[p for c in self._convs() for p in (c.weight, c.bias)])
         cpu = ops.UNIT_CHANNELS[dtype]
         units = (self.in_channels + 4 * self.growth_channels) // cpu
         buf = ops.to_blocked(x, units, dtype)
@@ -134,8 +188,12 @@ class RRDB(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
-        _no_grad_only(self, x)
         dtype = _PRECISIONS[self.precision]
+        if _records_graph(self, x):
+            if dtype != DTYPE_BF16:
+                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+            params = [p for r in (self.rdb1, self.rdb2, self.rdb3) for c in r._convs() for p in (c.weight, c.bias)]
+            return _BlockFunction.apply(x.float().contiguous(), self, *params)
         cpu = ops.UNIT_CHANNELS[dtype]
         units = (self.in_channels + 4 * self.growth_channels) // cpu
         cur = ops.to_blocked(x, units, dtype)
@@ -386,8 +444,53 @@ def _check_input(x: Tensor, channels: int) -> None:
                            "'cuda' (there is no CPU fallback)")
 
 
-def _no_grad_only(module: nn.Module, x: Tensor) -> None:
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters())):
-        raise NotImplementedError(
-            "the HIP backward (dgrad/wgrad) kernels are not wired yet: call under torch.no_grad() "
-            "or with requires_grad_(False) parameters")
+def _records_graph(module: nn.Module, x: Tensor) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+class _BlockFunction(torch.autograd.Function):
+    """Autograd node of a stand-alone ``ResidualDenseBlock`` or ``RRDB``
+    (/root/reference/esrgan/models/esrgan_model.py:18-24, :35-39): the forward keeps one blocked buffer per dense
+    block, the backward runs each block's five data gradients (one launch for images up to 32 pixels wide) and its
+    five weight gradients on the same kernels the generator's backward uses."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, module, *params: Tensor) -> Tensor:
+        blocks = [module] if isinstance(module, ResidualDenseBlock) else [module.rdb1, module.rdb2, module.rdb3]
+        nf, gc = blocks[0].in_channels, blocks[0].growth_channels
+        units = (nf + 4 * gc) // 8
+        xd = x.detach()
+        bufs = [ops.to_blocked(xd, units, DTYPE_BF16)] + [torch.empty((x.shape[0], x.shape[2], units, x.shape[3], 8),
+                                                                       dtype=torch.bfloat16, device=x.device)
+                                                           for _ in blocks]
+        outer = ops.to_blocked(xd, nf // 4, DTYPE_F32)            # fp32 input (the RRDB skip reads it)
+        trunk = torch.empty_like(outer)
+        if len(blocks) == 1:
+            blocks[0]._run(bufs[0], outer, trunk, bufs[1], DTYPE_BF16)
+            out = trunk
+        else:
+            blocks[0]._run(bufs[0], outer, trunk, bufs[1], DTYPE_BF16)
+            blocks[1]._run(bufs[1], trunk, trunk, bufs[2], DTYPE_BF16)
+            blocks[2]._run(bufs[2], trunk, None, bufs[3], DTYPE_BF16, outer=outer, outer_out=outer)
+            out = outer
+        ctx.module, ctx.blocks, ctx.bufs = module, blocks, bufs[:len(blocks)]
+        ctx.need_x = x.requires_grad
+        return ops.from_blocked(out, 0, nf)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.float().contiguous()
+        blocks, bufs = ctx.blocks, ctx.bufs
+        if len(blocks) == 1:
+            grads: List[Tensor] = []
+            dx = g + blocks[0]._backward(bufs[0], g, 1.0, grads)
+        else:
+            # out = x + 0.2 * rdb3(rdb2(rdb1(x))): d3 = 0.2 g + 0.2 J3^T g, d2 = d3 + J2^T d3, d1 = d2 + J1^T d2
+            s = ctx.module.res_scale
+            g3, g2, g1 = [], [], []
+            d3 = s * g + blocks[2]._backward(bufs[2], g, s, g3)
+            d2 = d3 + blocks[1]._backward(bufs[1], d3, 1.0, g2)
+            d1 = d2 + blocks[0]._backward(bufs[0], d2, 1.0, g1)
+            dx = g + d1
+            grads = g1 + g2 + g3
+        return (dx if ctx.need_x else None, None, *grads)

@@ -36,10 +36,18 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  reduce_group=None):
         self._reduce_group = reduce_group
+        self._pending = None
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._groups: List[_Group] = [self._flatten(g) for g in self.param_groups]
+
+    def add_param_group(self, param_group) -> None:
+        """``torch.optim.Optimizer.add_param_group`` (fine-tuning: unfreeze a layer and hand it to the optimizer):
+        the new group gets a flat buffer of its own."""
+        super().add_param_group(param_group)
+        if hasattr(self, "_groups"):          # the base constructor adds the initial groups through this method too
+            self._groups.append(self._flatten(self.param_groups[-1]))
 
     # -- set-up ---------------------------------------------------------------------------
     def _flatten(self, group) -> _Group:
@@ -123,21 +131,54 @@ class FlatAdam(torch.optim.Optimizer):
         torch._foreach_copy_(views, grads)
         return fg.scratch
 
+    @staticmethod
+    def _check_views(fg: _Group, every: bool) -> None:
+        """The update writes ``fg.flat``; it reaches the module only while every parameter still is a view of it.
+        ``module.to(...)``, ``.half()`` or assigning ``p.data`` after the optimizer was built break that silently."""
+        base = fg.flat.data_ptr()
+        idx = range(len(fg.params)) if every else (0, len(fg.params) - 1)
+        for i in idx:
+            if fg.params[i].data_ptr() != base + 4 * fg.offsets[i]:
+                raise RuntimeError("FlatAdam: a parameter no longer aliases the optimizer's flat buffer (the module was "
+                                   "moved, cast or had .data reassigned after the optimizer was built); rebuild the "
+                                   "optimizer after such a change")
+
+    @torch.no_grad()
+    def begin_step(self) -> None:
+        """Optional first half of ``step()`` for an optimizer with a ``reduce_group``: starts the all-reduce of the
+        gradients and returns without waiting, so that work the caller enqueues between ``begin_step()`` and
+        ``step()`` (anything that needs neither these gradients nor the updated parameters) runs while the
+        collective is in flight.  ``step()`` then waits for it and applies the update.  A no-op without a group."""
+        if self._reduce_group is None or self._pending is not None:
+            return
+        from .ddp import start_all_reduce_mean
+        self._pending = []
+        for fg in self._groups:
+            grad = self._flat_grad(fg) if fg.flat is not None else None
+            self._pending.append((grad, start_all_reduce_mean(grad, self._reduce_group) if grad is not None else None))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group, fg in zip(self.param_groups, self._groups):
+        pending, self._pending = self._pending, None
+        for i, (group, fg) in enumerate(zip(self.param_groups, self._groups)):
             if fg.flat is None:
                 continue
-            grad = self._flat_grad(fg)
+            if pending is not None and i < len(pending):
+                grad, handle = pending[i]
+                if handle is not None:
+                    handle.wait()                                            # in place: .grad holds the mean after it
+            else:
+                grad = self._flat_grad(fg)
+                if grad is not None and self._reduce_group is not None:
+                    from .ddp import all_reduce_mean
+                    all_reduce_mean(grad, self._reduce_group)
             if grad is None:
                 continue
-            if self._reduce_group is not None:
-                from .ddp import all_reduce_mean
-                all_reduce_mean(grad, self._reduce_group)                    # in place: .grad holds the mean after it
+            self._check_views(fg, every=fg.step % 128 == 0)          # all of them now and then, the ends every step
             fg.step += 1
             fg.step_t.fill_(float(fg.step))
             b1, b2 = group["betas"]

@@ -1,8 +1,9 @@
-"""CPU (gloo, world_size 2): bucket planning and the overlap orchestration of the data-parallel backward,
-with a stand-in for the HIP phase executor."""
+"""CPU (gloo, world_size 2 and 3): bucket planning and the overlap orchestration of the data-parallel backward,
+with a stand-in for the HIP phase executor; the started-then-awaited mean the discriminator's optimizer uses."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -81,3 +82,46 @@ def test_bucketed_all_reduce_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["ok"] and ret["order"] and ret["buckets"] >= 2
+
+
+def _worker_wrapped(rank, world, port, bucket_mb, ret):
+    """The bucket plan of ``DistributedGenerator`` itself (3 RRDBs: 2.2 M floats) at ``bucket_mb``, ranks with
+    different gradients, uneven world size."""
+    import super_resolution_amd as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wrapped = ddp.DistributedGenerator(S.GeneratorRRDB(num_blocks=3), bucket_mb=bucket_mb)
+    sl, buckets = wrapped.slices, wrapped.buckets
+    n = sl[0][1]
+    gen = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(n, generator=gen)
+    flat = torch.full((n,), float("nan"))
+    calls = []
+
+    def run_phases(pb, pe):
+        calls.append((pb, pe))
+        for p in range(pb, pe):
+            lo, hi = sl[p]
+            flat[lo:hi] = mine[lo:hi]
+
+    ddp.reduce_in_buckets(flat, buckets, run_phases)
+    expect = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+    # the discriminator's path: start the mean, do other work, wait
+    t = torch.full((1000,), float(rank + 1))
+    pending = ddp.start_all_reduce_mean(t)
+    other = sum(range(1000))                      # stands for the kernels enqueued while the collective runs
+    pending.wait()
+    if rank == world - 1:
+        ret["ok"] = bool(torch.allclose(flat, expect, rtol=1e-6, atol=1e-7))
+        ret["calls"] = calls == [(b[0], b[1]) for b in buckets]
+        ret["buckets"] = len(buckets)
+        ret["mean"] = bool(torch.equal(t, torch.full((1000,), (world + 1) / 2.0))) and other == 499500
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mb,n_buckets", [(1.0, 4), (16.0, 1), (float("inf"), 1)])
+def test_wrapped_generator_bucket_sizes_three_ranks(bucket_mb, n_buckets):
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_wrapped, args=(3, _free_port(), bucket_mb, ret), nprocs=3, join=True)
+    assert ret["ok"] and ret["calls"] and ret["mean"]
+    assert ret["buckets"] == n_buckets
