@@ -14,7 +14,10 @@ Besides the throughput the line carries
   algorithmic FLOPs of its launches in one forward divided by their measured durations
   (HIP events on the launch stream), against the 2.5 PFLOP/s dense bf16 peak;
 * ``cpu_baseline``: the CPU oracle (a port of the reference PyTorch forward) timed on this
-  box's host cores on one patch of the same workload.
+  box's host cores on BASELINE configs[0] (batch 4 of 3x64x64);
+* ``other_configs``: the remaining BASELINE configurations (510x339 image whole / tiled / sharded,
+  CycleGAN GeneratorSR, conditional VAE), ``strong_scaling`` (N > 1: the headline batch split over the
+  ranks) and ``train`` (pixel and adversarial iterations) as extras.
 """
 import argparse
 import json
@@ -209,11 +212,14 @@ def host_buffer_rate(net, B, H, W, dev, steps=20):
                     "copy/compute overlap between steps"}
 
 
-def cpu_baseline(H, W):
-    """The oracle on the host cores, one patch of the benchmark workload (same generator, fp32)."""
+def cpu_baseline():
+    """The oracle (a port of the reference PyTorch forward, fp32) on the host cores, on BASELINE configs[0] as it stands:
+    one batch of 4 LR patches of 3x64x64 (the reference's own CPU-runnable case; the same pixel count as one of the
+    sixteen 128x128 patches of the headline workload, and the generator is fully convolutional)."""
     from oracle import esrgan_oracle as O
     sd = O.make_generator_state(0)
-    x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(1234))
+    B, H, W = 4, 64, 64
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1234))
     cores = torch.get_num_threads()
     with torch.no_grad():
         O.generator_forward(sd, x)           # warm-up
@@ -224,9 +230,99 @@ def cpu_baseline(H, W):
             O.generator_forward(sd, x)
             times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(16 * H * W / med / 1e6, 4), "unit": "HR Mpix/s", "cores": cores, "kind": "port",
-            "sample": f"1 of the 16 patches (1x3x{H}x{W} fp32), median of {len(times)} forwards after 1 warm-up, "
-                      f"{med:.3f} s each, torch CPU threads={cores}"}
+    return {"value": round(B * 16 * H * W / med / 1e6, 4), "unit": "HR Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"configs[0]: batch {B} of 3x{H}x{W} fp32 LR patches, median of {len(times)} forwards after 1 "
+                      f"warm-up, {med:.3f} s each, torch CPU threads={cores}"}
+
+
+def _rate(fn, steps, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def other_configs(net, dev, world, rank, dist):
+    """The BASELINE configurations besides the headline one, as extras of the same JSON line:
+    configs[0] (batch 4 of 64x64, the CPU case) on the GPU; configs[3] (a DIV2K-size 510x339 LR image -> 2040x1356)
+    whole, as four row bands with a 16-row halo on one GPU, and sharded by bands across the ranks with the final
+    gather (N > 1); configs[4] (CycleGAN GeneratorSR and the conditional VAE on the same conv kernels)."""
+    import super_resolution_amd as S
+    out = {}
+    with torch.no_grad():
+        if rank == 0:
+            x0 = torch.rand(4, 3, 64, 64, device=dev)
+            sec = _rate(lambda: net(x0), 20)
+            out["configs[0] batch 4 of 3x64x64 on one GPU"] = {"value": round(4 * 16 * 64 * 64 / sec / 1e6, 2),
+                                                               "unit": "HR Mpix/s", "ms_per_step": round(sec * 1e3, 3)}
+        img = torch.rand(1, 3, 339, 510, generator=torch.Generator().manual_seed(99)).to(dev)
+        hr_mpix = 16 * 339 * 510 / 1e6
+        if rank == 0:
+            sec = _rate(lambda: net(img), 5, 1)
+            whole = net(img)
+            out["configs[3] 510x339 whole image on one GPU"] = {"value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s",
+                                                                "ms_per_image": round(sec * 1e3, 2)}
+            sec = _rate(lambda: S.tiled_forward(net, img, 4, 16), 5, 1)
+            tiled = S.tiled_forward(net, img, 4, 16)
+            out["configs[3] 510x339 as 4 row bands, halo 16, on one GPU"] = {
+                "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
+                "max_abs_vs_whole": float((tiled - whole).abs().max())}
+            del whole, tiled
+        if world > 1:
+            def sharded():
+                return S.sharded_forward(net, img, halo=16)
+            for _ in range(2):
+                sharded()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                sharded()
+            dist.barrier()
+            torch.cuda.synchronize()
+            sec = _max_over_ranks((time.perf_counter() - t0) / 5, dev, dist)
+            out[f"configs[3] 510x339 sharded by row bands over {world} GPUs (halo 16, gather on rank 0)"] = {
+                "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
+                "scaling": "strong"}
+        if rank == 0:
+            gsr = S.cyclegan.GeneratorSR().to(dev).eval()
+            xg = torch.rand(16, 3, 64, 64, device=dev) * 2 - 1
+            sec = _rate(lambda: gsr(xg), 20)
+            y = gsr(xg)
+            out["configs[4] CycleGAN GeneratorSR (6 residual blocks), batch 16 of 3x64x64"] = {
+                "value": round(16 * y.shape[2] * y.shape[3] / sec / 1e6, 2), "unit": "HR Mpix/s",
+                "ms_per_step": round(sec * 1e3, 3), "out": list(y.shape)}
+            vae = S.cvae.CVAE().to(dev).eval()
+            xv = torch.rand(16, 3, 32, 32, device=dev)
+            sec = _rate(lambda: vae(xv), 20)
+            yv = vae(xv)[0]
+            out["configs[4] conditional VAE forward (encode, reparameterise, decode), batch 16 of 3x32x32"] = {
+                "value": round(16 / sec, 1), "unit": "images/s", "ms_per_step": round(sec * 1e3, 3), "out": list(yv.shape)}
+    return out
+
+
+def strong_scaling(net, dev, world, dist, B, H, W, steps):
+    """The headline batch split over the ranks (fixed total work): every rank runs B / world patches."""
+    if world == 1 or B % world:
+        return None
+    x = torch.rand(B // world, 3, H, W, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            net(x)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(x)
+        dist.barrier()
+        torch.cuda.synchronize()
+    el = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+    return {"value": round(B * 16 * H * W * steps / el / 1e6, 2), "unit": "HR Mpix/s", "ms_per_step": round(el / steps * 1e3, 3),
+            "scaling": "strong", "global_batch": B, "batch_per_gpu": B // world}
 
 
 def _max_over_ranks(seconds, dev, dist):
@@ -356,8 +452,9 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
         assert bool(torch.isfinite(losses["loss_G"])) and bool(torch.isfinite(losses["loss_D"]))
         out["adversarial_step"] = {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
                                    "ms_per_step": round(el / steps * 1e3, 2),
-                                   "scope": "D update + G update (two G forwards, one G backward, three D forwards, "
-                                            "two D backwards, two VGG19 forwards, one VGG19 data-gradient), Adam on both"}
+                                   "scope": "D update + G update (one recorded G forward serving both, one G backward, three "
+                                            "D forwards, two D backwards plus one data-gradient-only pass, two VGG19 "
+                                            "forwards, one VGG19 data-gradient), Adam on both"}
     except Exception as exc:
         out["adversarial_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
@@ -373,6 +470,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the extra training-step figure")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other BASELINE configurations and strong scaling")
     ap.add_argument("--train-graph", action="store_true",
                     help="also replay the pixel iteration from a captured HIP graph (measured slower than eager issue: "
                          "about 3,000 graph nodes per step)")
@@ -461,12 +559,21 @@ def main():
             line["roofline_other_kernels"] = other
             line["kernel_shapes"] = per_shape
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(H, W)
+            line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_roofline:
             try:
                 line["pcie_inclusive"] = host_buffer_rate(net, B, H, W, dev)
             except Exception as exc:      # an extra: the headline number stands on its own
                 line["pcie_inclusive"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if not args.no_extras:
+        try:
+            if world > 1:
+                line["strong_scaling"] = strong_scaling(net, dev, world, dist, B, H, W, max(5, args.steps // 2))
+            extras = other_configs(net, dev, world, rank, dist)
+            if rank == 0:
+                line["other_configs"] = extras
+        except Exception as exc:          # extras: the headline number stands on its own
+            line["other_configs"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
     hung = False
     if not args.no_train:
         del out

@@ -29,68 +29,87 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Four sums at once (the four channels of a quad): two barriers instead of eight.
+__device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16] */) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_down(v[j], o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[4 * wave + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = red[j] + red[4 + j] + red[8 + j] + red[12 + j];
+}
+
+// Sum over the 64 lanes of a wave in a fixed order, result in every lane.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// BatchNorm statistics.  x is an fp32 trunk tensor [rows = N*H][C/4][W][4].  Workgroup (part p, quad cq) sums the
-// rows p, p + parts, ... of the four channels of quad cq.
-__global__ void bn_partial_sum_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
-                                      float *__restrict__ psum /* [parts][4Q] */) {
-    __shared__ float red[4];
+// BatchNorm statistics.  x is an fp32 trunk tensor [rows = N*H][C/4][W][4].  Workgroup (part p, quad cq) owns the
+// rows p, p + parts, ... of the four channels of quad cq, all 256 threads striding over their (row, pixel) items.
+// It writes the mean of ITS items and the sum of squared deviations from that mean (the second loop re-reads what the
+// first one just pulled into L2).  E[x^2] - E[x]^2 in fp32 would lose the variance of a channel whose mean dominates
+// it; per-part means combined afterwards (Chan et al.) do not.
+__device__ __forceinline__ int bn_part_rows(int rows, int parts, int p) { return (rows - p + parts - 1) / parts; }
+
+__global__ void bn_partial_stats_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
+                                        float *__restrict__ pmean /* [parts][4Q] */, float *__restrict__ pm2) {
+    __shared__ float red[16];
     const int cq = blockIdx.y, p = blockIdx.x;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = p; row < rows; row += parts) {
-        const float4 *src = x + ((size_t)row * Q + cq) * W;
-        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
-            const float4 v = src[i];
-            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
-        }
+    const int items = bn_part_rows(rows, parts, p) * W;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
+        const int r = i / W, px = i - r * W;
+        const float4 v = x[((size_t)(p + r * parts) * Q + cq) * W + px];
+        s[0] += v.x, s[1] += v.y, s[2] += v.z, s[3] += v.w;
     }
-    const float a = block_sum(s.x, red), b = block_sum(s.y, red), c = block_sum(s.z, red), d = block_sum(s.w, red);
-    if (threadIdx.x == 0) {
-        float *o = psum + (size_t)p * 4 * Q + 4 * cq;
-        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
+    block_sum4(s, red);
+    const float inv = 1.0f / (float)items;
+    const float mean[4] = {s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv};
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
+        const int r = i / W, px = i - r * W;
+        const float4 v = x[((size_t)(p + r * parts) * Q + cq) * W + px];
+        const float a = v.x - mean[0], b = v.y - mean[1], c = v.z - mean[2], d = v.w - mean[3];
+        q[0] += a * a, q[1] += b * b, q[2] += c * c, q[3] += d * d;
+    }
+    block_sum4(q, red);
+    if (threadIdx.x < 4) {
+        pmean[(size_t)p * 4 * Q + 4 * cq + threadIdx.x] = mean[threadIdx.x];
+        pm2[(size_t)p * 4 * Q + 4 * cq + threadIdx.x] = q[threadIdx.x];
     }
 }
 
-// Second pass: sum of squared deviations from the mean the first pass gives (two passes: E[x^2] - E[x]^2 in fp32
-// loses the variance of a channel whose mean dominates it).
-__global__ void bn_partial_var_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
-                                      const float *__restrict__ psum, float inv_m, float *__restrict__ psq) {
-    __shared__ float red[4];
-    const int cq = blockIdx.y, p = blockIdx.x;
-    float mean[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < parts; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mean[j] += psum[(size_t)k * 4 * Q + 4 * cq + j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mean[j] *= inv_m;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = p; row < rows; row += parts) {
-        const float4 *src = x + ((size_t)row * Q + cq) * W;
-        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
-            const float4 v = src[i];
-            const float a = v.x - mean[0], b = v.y - mean[1], c = v.z - mean[2], d = v.w - mean[3];
-            s.x += a * a, s.y += b * b, s.z += c * c, s.w += d * d;
-        }
-    }
-    const float a = block_sum(s.x, red), b = block_sum(s.y, red), c = block_sum(s.z, red), d = block_sum(s.w, red);
-    if (threadIdx.x == 0) {
-        float *o = psq + (size_t)p * 4 * Q + 4 * cq;
-        o[0] = a, o[1] = b, o[2] = c, o[3] = d;
-    }
-}
-
-// One thread per channel: batch mean / 1/sqrt(var + eps) for the apply pass, and the running buffers as
-// nn.BatchNorm2d keeps them (momentum update with the unbiased variance, batch counter).
-__global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int parts, int C, float m,
-                                   float eps, float momentum, float *__restrict__ running_mean,
+// One wave per channel, one lane per part (parts <= 64): batch mean / 1/sqrt(var + eps) for the apply pass, and the
+// running buffers as nn.BatchNorm2d keeps them (momentum update with the unbiased variance, batch counter).
+__global__ void bn_finalize_kernel(const float *__restrict__ pmean, const float *__restrict__ pm2, int parts, int C, int rows,
+                                   int W, float m, float eps, float momentum, float *__restrict__ running_mean,
                                    float *__restrict__ running_var, long long *__restrict__ num_batches,
                                    float *__restrict__ save_mean, float *__restrict__ save_rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches) *num_batches += 1;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
     if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < parts; ++k) s += psum[(size_t)k * C + c], q += psq[(size_t)k * C + c];
-    const float mean = s / m, var = q / m;
+    float n_k = 0.f, mean_k = 0.f, m2_k = 0.f;
+    if (lane < parts) {
+        n_k = (float)(bn_part_rows(rows, parts, lane) * W);
+        mean_k = pmean[(size_t)lane * C + c];
+        m2_k = pm2[(size_t)lane * C + c];
+    }
+    const float mean = wave_sum(n_k * mean_k) / m;
+    const float dlt = mean_k - mean;
+    const float q = wave_sum(m2_k + n_k * dlt * dlt);
+    if (lane) return;
+    const float var = q / m;
     save_mean[c] = mean;
     save_rstd[c] = 1.0f / sqrtf(var + eps);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -141,45 +160,47 @@ __global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const __bf16
                                       const float *__restrict__ rstd, const float *__restrict__ gamma,
                                       const float *__restrict__ beta, float slope, float *__restrict__ pg,
                                       float *__restrict__ pgx) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int cq = blockIdx.y, p = blockIdx.x;
     float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mu[j] = mean[4 * cq + j], rs[j] = rstd[4 * cq + j], ga[j] = gamma[4 * cq + j], be[j] = beta[4 * cq + j];
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int row = p; row < rows; row += parts) {
-        const float4 *src = x + ((size_t)row * Q + cq) * W;
-        const __bf16 *gsrc = dy + (((size_t)row * dy_units + dy_unit_off + (cq >> 1)) * W) * 8 + (cq & 1) * 4;
-        for (int i = threadIdx.x; i < W; i += AUX_THREADS) {
-            const float4 xv = src[i];
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            uint2 raw = *reinterpret_cast<const uint2 *>(gsrc + (size_t)i * 8);
-            __bf16 gv[4];
-            __builtin_memcpy(gv, &raw, 8);
+    const int items = bn_part_rows(rows, parts, p) * W;
+    for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
+        const int r = i / W, px = i - r * W;
+        const size_t row = (size_t)(p + r * parts);
+        const float4 xv = x[(row * Q + cq) * W + px];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const uint2 raw = *reinterpret_cast<const uint2 *>(dy + ((row * dy_units + dy_unit_off + (cq >> 1)) * W + px) * 8 +
+                                                           (cq & 1) * 4);
+        __bf16 gv[4];
+        __builtin_memcpy(gv, &raw, 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (xs[j] - mu[j]) * rs[j];
-                const float z = ga[j] * xh + be[j];
-                const float g = (float)gv[j] * (z > 0.f ? 1.f : slope);
-                sg[j] += g, sx[j] += g * xh;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xs[j] - mu[j]) * rs[j];
+            const float z = ga[j] * xh + be[j];
+            const float g = (float)gv[j] * (z > 0.f ? 1.f : slope);
+            sg[j] += g, sx[j] += g * xh;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = block_sum(sg[j], red), b = block_sum(sx[j], red);
-        if (threadIdx.x == 0) pg[(size_t)p * 4 * Q + 4 * cq + j] = a, pgx[(size_t)p * 4 * Q + 4 * cq + j] = b;
+    block_sum4(sg, red);
+    block_sum4(sx, red);
+    if (threadIdx.x < 4) {
+        pg[(size_t)p * 4 * Q + 4 * cq + threadIdx.x] = sg[threadIdx.x];
+        pgx[(size_t)p * 4 * Q + 4 * cq + threadIdx.x] = sx[threadIdx.x];
     }
 }
 
+// One wave per channel, one lane per part.
 __global__ void bn_bwd_finalize_kernel(const float *__restrict__ pg, const float *__restrict__ pgx, int parts, int C,
                                        float *__restrict__ dbeta, float *__restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int k = 0; k < parts; ++k) s += pg[(size_t)k * C + c], q += pgx[(size_t)k * C + c];
-    dbeta[c] = s;
-    dgamma[c] = q;
+    const float s = wave_sum(lane < parts ? pg[(size_t)lane * C + c] : 0.f);
+    const float q = wave_sum(lane < parts ? pgx[(size_t)lane * C + c] : 0.f);
+    if (lane == 0) dbeta[c] = s, dgamma[c] = q;
 }
 
 // Backward, pass 2: dx = gamma * rstd * (g - dbeta / m - xhat * dgamma / m) in training mode (the batch statistics
@@ -356,13 +377,11 @@ int launch_bn_lrelu_fwd(const float *x, int N, int H, int W, int C, const float 
     const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
     const float m = (float)((double)N * H * W);
     if (training) {
-        float *psum = workspace, *psq = workspace + (size_t)parts * C;
-        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows, Q,
-                           W, parts, psum);
-        hipLaunchKernelGGL(bn_partial_var_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows, Q,
-                           W, parts, psum, 1.0f / m, psq);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, psum, psq, parts, C, m, eps,
-                           momentum, running_mean, running_var, num_batches, save_mean, save_rstd);
+        float *pmean = workspace, *pm2 = workspace + (size_t)parts * C;
+        hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows,
+                           Q, W, parts, pmean, pm2);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, parts, C, rows, W, m,
+                           eps, momentum, running_mean, running_var, num_batches, save_mean, save_rstd);
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var, C,
                            eps, save_mean, save_rstd);
@@ -383,8 +402,7 @@ int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_uni
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
                        (const __bf16 *)dy, dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope,
                        pg, pgx);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pg, pgx, parts, C, dbeta,
-                       dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pg, pgx, parts, C, dbeta, dgamma);
     const size_t n_items = (size_t)rows * U * W;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
                        (const __bf16 *)dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta, dbeta,

@@ -190,7 +190,17 @@ def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, 
         feat_sr, feat_hr = vgg(fake), vgg(hr)
         optim_D.step()
 
-    pred_fake = netD(fake)
+    # The generator's loss needs the discriminator's input gradient only.  The reference's loss_G.backward() (:220) also
+    # accumulates gradients into netD's parameters, which nothing reads: the next iteration starts with
+    # optim_D.zero_grad() (:197).  They are not computed here (a third of the discriminator's weight-gradient work).
+    d_params = [p for p in netD.parameters() if p.requires_grad]
+    for p in d_params:
+        p.requires_grad_(False)
+    try:
+        pred_fake = netD(fake)
+    finally:
+        for p in d_params:
+            p.requires_grad_(True)
     loss_G_gan = cc.mse_loss(pred_fake, 1.0)
     loss_G_pix = cc.l1_loss(fake, hr)
     loss_G_per = cc.l1_loss(feat_sr, feat_hr)
