@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -86,7 +87,8 @@ static std::vector<ConvSpec> conv_specs(const sr355_generator_cfg &c, size_t *to
 }
 
 struct Workspace {
-    size_t x0, bufA, bufB, T, R, F, L1, H1, H2, H3, total;
+    size_t x0, bufA, bufB, T, R, F, L1, H1, H2, H3, chain_flags, chain_table, total;
+    size_t chain_flag_bytes;
     int in_units, nf_units, blk_units, f32_units;
 };
 
@@ -115,6 +117,11 @@ static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
     w.H1 = take(4 * P * w.nf_units * 16);
     w.H2 = take(16 * P * w.nf_units * 16);
     w.H3 = take(16 * P * w.nf_units * 16);
+    // the chain kernel's per-tile pass counters (+ its error word; a block of its own, a multiple of 16 bytes) and its
+    // table of passes: six per dense block, two for trunk_conv
+    w.chain_flag_bytes = ((size_t)N * ((H + 15) / 16) * ((W + 31) / 32) + 1 + 3) / 4 * 16;
+    w.chain_flags = take(w.chain_flag_bytes);
+    w.chain_table = take((size_t)(18 * c.num_blocks + 2) * sizeof(ChainPass));
     w.total = off;
     return w;
 }
@@ -692,6 +699,9 @@ struct FwdBufs {
     int blk_count;       // 2 = ping-pong, otherwise 3*num_blocks + 1 distinct buffers
     float *T, *R, *F;
     unsigned char *L1, *H1, *H2, *H3;
+    unsigned *chain_flags = nullptr;      // chain kernel state (inference workspace only)
+    size_t chain_flag_bytes = 0;
+    ChainPass *chain_table = nullptr;
     unsigned char *blk(int i) const { return blk_base + (size_t)(blk_count == 2 ? (i & 1) : i) * blk_stride; }
 };
 
@@ -748,6 +758,33 @@ static bool use_dense_fused(const sr355_generator_cfg *cfg, int N, int H, int W)
     return (long long)N * ((H + 1) / 2) <= max_bands;
 }
 
+// The body (every dense block and trunk_conv) as one persistent launch (conv3x3_chain.hip) where 16-row tiles give every
+// CU work: large batches / images.  SR355_CHAIN=0 keeps one launch per conv.
+static bool use_chain(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    const char *e = getenv("SR355_CHAIN");      // read on every call: tests compare the two paths in one process
+    const int knob = e ? atoi(e) : 1;
+    if (!knob || cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features != 64 || cfg->growth_channels != 32) return false;
+    int slots = 0;
+    if (chain_resident_workgroups(&slots) || slots < 2) return false;
+    return (long long)N * ((H + 15) / 16) * ((W + 31) / 32) >= slots / 2;
+}
+
+// The word the chain kernel raises when a wait gave up, copied back after every chain launch and looked at by the
+// next call: pinned host memory, one word per device.
+static unsigned *chain_err_host(int dev) {
+    static std::once_flag once[64];
+    static unsigned *word[64] = {};
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::call_once(once[dev], [dev] {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) {
+            *(volatile unsigned *)p = 0;
+            word[dev] = (unsigned *)p;
+        }
+    });
+    return word[dev];
+}
+
 // Input: fp32 NCHW, or (in_u8) a uint8 HWC image batch read as byte / 255.  Output: fp32 NCHW unclamped, or (out_u8)
 // the uint8 HWC image batch the reference's inference saves (clamp, mul 255, truncate).
 static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpec> &specs, const unsigned char *pk,
@@ -765,8 +802,17 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                                             stream);
     if (rc) return rc;
 
-    // parts of the batch and the stream each runs on
-    int n_parts = dtype == SR355_DTYPE_BF16 ? batch_parts(N, H, W) : 1;
+    const bool fused = use_dense_fused(cfg, N, H, W);
+    const bool chain = !fused && fb.chain_table && use_chain(cfg, N, H, W);
+    struct ChainConv {
+        ConvArgs a;
+        int cin_units;
+        bool all_stages;      // every stage reads the previous conv's output (a block's first conv, trunk_conv)
+    };
+    std::vector<ChainConv> chain_convs;
+    bool chain_collect = false, chain_all = false;
+    // parts of the batch and the stream each runs on (the chain kernel keeps the whole batch in one launch)
+    int n_parts = dtype == SR355_DTYPE_BF16 && !chain ? batch_parts(N, H, W) : 1;
     int part_n0[MAX_PARTS] = {0}, part_n[MAX_PARTS] = {N};
     hipStream_t part_stream[MAX_PARTS] = {stream};
     SideStream *ss = n_parts > 1 ? side_stream() : nullptr;
@@ -825,6 +871,14 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             a.f16_in = sp.f16;
             // a blocked output that the next conv reads as fp16: every conv in front of an fp16 one
             a.f16_out = (out_act && ci < specs.size() && specs[ci].f16) ? 1 : 0;
+            if (chain_collect) {
+                if (!chain_supported(a, cin_units) || sp.split != SR355_SPLIT_NONE) {
+                    set_error("generator forward: a conv of the body does not fit the chain kernel");
+                    return SR355_ERR_UNSUPPORTED;
+                }
+                chain_convs.push_back({a, cin_units, chain_all});
+                continue;
+            }
             const int rc_ = launch_conv3x3(a, dtype, cin_units, sp.split != SR355_SPLIT_NONE, part_stream[p]);
             if (rc_) return rc_;
         }
@@ -832,7 +886,6 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     };
 
     // one dense block (:18-24) as a single launch; conv5's epilogue arguments as in `conv`
-    const bool fused = use_dense_fused(cfg, N, H, W);
     auto dense = [&](unsigned char *cur, unsigned char *nxt, const float *res1, float s1, const float *res2, float s2,
                      float *out_f32, bool res_from_act) -> int {
         const size_t blk_img = (size_t)H * W * ws.blk_units * 16;
@@ -876,6 +929,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
     if ((rc = conv(fb.x0, ws.in_units, ws.in_units, H, W, 0, fb.blk(0), ws.blk_units, 0, 1.f, nullptr, 0.f, nullptr,
                    0.f, F, nullptr)))
         return rc;
+    chain_collect = chain;
     for (int b = 0; b < cfg->num_blocks; ++b) {
         const float *rrdb_in = (b == 0) ? F : R;  // fp32 input of this RRDB (:35)
         for (int r = 0; r < 3; ++r, ++bi) {
@@ -891,11 +945,13 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                 continue;
             }
             for (int k = 0; k < 4; ++k) {  // growth convs (:19-22): read [0, nf+k*gc), append gc channels
+                chain_all = k == 0;
                 if ((rc = conv(cur, ws.blk_units, (nf + k * gc) / cpu, H, W, 0, cur, ws.blk_units,
                                (nf + k * gc) / cpu, 0.2f, nullptr, 0.f, nullptr, 0.f, nullptr, nullptr)))
                     return rc;
             }
             // conv5 + dense skip (:23-24); the third block also folds the RRDB skip (:39).
+            chain_all = false;
             if (rrdb_only) {
                 // the dense skip reads the bf16 activations (units [0, nf) of this block's buffer); only the RRDB skip
                 // keeps an fp32 carrier
@@ -919,9 +975,92 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         }
     }
     // trunk_conv + global skip (:57-58)
+    chain_all = true;
     if ((rc = conv(fb.blk(bi), ws.blk_units, ws.nf_units, H, W, 0, fb.L1, ws.nf_units, 0, 1.f, F, 1.f, nullptr, 0.f,
                    nullptr, nullptr)))
         return rc;
+    if (chain) {
+        // The collected convs as passes of 32 output channels.  A pass's `need` is its own index: everything before it.
+        chain_collect = false;
+        std::vector<ChainPass> passes;
+        for (const ChainConv &cc : chain_convs) {
+            const int S = cc.cin_units / 2;
+            for (int cb = 0; cb < cc.a.cout_pad / 32; ++cb) {
+                ChainPass ps;
+                memset(&ps, 0, sizeof(ps));
+                ps.a = cc.a;
+                ps.a.n_stages = ps.a.n_real_stages = S;
+                ps.a.w = cc.a.w + (size_t)cb * 32 * 16;
+                ps.a.bias = cc.a.bias + cb * 32;
+                ps.cb_co = cb * 32;
+                ps.need = (int)passes.size();
+                // the second block of output channels reads what the first one read: nothing new to wait for
+                ps.dep_stage = cb ? S : (cc.all_stages ? 0 : S - 2);
+                if (passes.empty()) ps.dep_stage = S;      // the chain's input comes from the launch before it
+                if (ps.dep_stage == 1 || S < 2) {
+                    set_error("generator forward: chain pass with %d stages cannot be ordered", S);
+                    return SR355_ERR_UNSUPPORTED;
+                }
+                passes.push_back(ps);
+            }
+        }
+        if (passes.size() * sizeof(ChainPass) > (size_t)(18 * cfg->num_blocks + 2) * sizeof(ChainPass)) {
+            set_error("generator forward: chain table overflow");
+            return SR355_ERR_INVALID;
+        }
+        int dev = 0;
+        if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+        unsigned *err_host = chain_err_host(dev);
+        if (err_host && *(volatile unsigned *)err_host) {
+            *(volatile unsigned *)err_host = 0;
+            set_error("generator forward: the previous call's chain kernel gave up waiting for a workgroup (its output "
+                      "was invalid)");
+            return SR355_ERR_HIP;
+        }
+        if (check_hip(hipMemcpyAsync(fb.chain_table, passes.data(), passes.size() * sizeof(ChainPass),
+                                     hipMemcpyHostToDevice, stream), "hipMemcpyAsync") ||
+            check_hip(hipMemsetAsync(fb.chain_flags, 0, fb.chain_flag_bytes, stream), "hipMemsetAsync"))
+            return SR355_ERR_HIP;
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.passes = fb.chain_table;
+        ca.n_passes = (int)passes.size();
+        ca.flags = fb.chain_flags;
+        ca.err = fb.chain_flags + fb.chain_flag_bytes / 4 - 1;
+        ca.N = N, ca.H = H, ca.W = W, ca.in_units = ws.blk_units;
+#ifdef SR355_TRACE
+        // timing builds: where wave 0 of every workgroup spent the launch (medians over the workgroups, microseconds)
+        static unsigned long long *trace_dev = nullptr;
+        if (getenv("SR355_CHAIN_TRACE")) {
+            if (!trace_dev && hipMalloc((void **)&trace_dev, 4096 * 64) != hipSuccess) trace_dev = nullptr;
+            ca.trace = trace_dev;
+        }
+#endif
+        if ((rc = launch_conv3x3_chain(ca, 0, stream))) return rc;
+#ifdef SR355_TRACE
+        if (ca.trace) {
+            static int calls = 0;
+            if (++calls == 5) {
+                std::vector<unsigned long long> t(4096 * 8);
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(t.data(), trace_dev, 4096 * 64, hipMemcpyDeviceToHost);
+                const char *names[8] = {"poll + acquire issue", "stage wait (DMA landed)", "stage barrier", "epilogue issue",
+                                        "restart (drain, publish, poll, acquire, first stage issue)", "acquire completion",
+                                        "first-stage wait of a pass (stores drain)", "total"};
+                const int nwg = 512;
+                for (int k = 0; k < 8; ++k) {
+                    std::vector<double> v;
+                    for (int b = 0; b < nwg; ++b) v.push_back(t[(size_t)b * 8 + k] * 0.01);
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "chain trace: %-60s p10 %9.1f median %9.1f p90 %9.1f us\n", names[k], v[nwg / 10],
+                            v[nwg / 2], v[nwg * 9 / 10]);
+                }
+            }
+        }
+#endif
+        if (err_host && check_hip(hipMemcpyAsync(err_host, ca.err, 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"))
+            return SR355_ERR_HIP;
+    }
     // nearest x2 + upconv1 + lrelu (:59), nearest x2 + upconv2 + lrelu (:60)
     if ((rc = conv(fb.L1, ws.nf_units, ws.nf_units, 2 * H, 2 * W, 1, fb.H1, ws.nf_units, 0, 0.2f, nullptr, 0.f,
                    nullptr, 0.f, nullptr, nullptr)))
@@ -981,6 +1120,8 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
     fb.blk_count = 2;
     fb.T = (float *)(wsb + ws.T), fb.R = (float *)(wsb + ws.R), fb.F = (float *)(wsb + ws.F);
     fb.L1 = wsb + ws.L1, fb.H1 = wsb + ws.H1, fb.H2 = wsb + ws.H2, fb.H3 = wsb + ws.H3;
+    fb.chain_flags = (unsigned *)(wsb + ws.chain_flags), fb.chain_flag_bytes = ws.chain_flag_bytes;
+    fb.chain_table = (ChainPass *)(wsb + ws.chain_table);
     return run_forward(cfg, specs, (const unsigned char *)packed, in_nchw, out_nchw, N, H, W, ws, fb,
                        (hipStream_t)stream_);
 }
@@ -1008,6 +1149,8 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
     fb.blk_count = 2;
     fb.T = (float *)(wsb + ws.T), fb.R = (float *)(wsb + ws.R), fb.F = (float *)(wsb + ws.F);
     fb.L1 = wsb + ws.L1, fb.H1 = wsb + ws.H1, fb.H2 = wsb + ws.H2, fb.H3 = wsb + ws.H3;
+    fb.chain_flags = (unsigned *)(wsb + ws.chain_flags), fb.chain_flag_bytes = ws.chain_flag_bytes;
+    fb.chain_table = (ChainPass *)(wsb + ws.chain_table);
     return run_forward(cfg, specs, (const unsigned char *)packed, nullptr, nullptr, N, H, W, ws, fb,
                        (hipStream_t)stream_, in_u8hwc, out_u8hwc);
 }

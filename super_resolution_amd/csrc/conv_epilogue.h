@@ -117,7 +117,9 @@ __device__ __forceinline__ bool conv_epilogue_tile_ok(const ConvArgs &a) {
     return !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0;
 }
 
-template <int MB, int NB>
+// AUX is the cache-policy operand of the stores: 0 = plain, 16 = write-through (sc1), which is what a kernel whose
+// workgroups read each other's output inside one launch needs.
+template <int MB, int NB, int AUX = 0>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16 (&acc)[MB][NB],
                                                    const unsigned char *bias_lds, int n, int y0, int x, int cb_co,
                                                    int h, bool live) {
@@ -204,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16
                 if (a.out_f32) {
                     const epi_v4f of = {v[0], v[1], v[2], v[3]};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_f32, vo_f,
-                                                           (mb * 8 + q * 2) * wstep, 0);
+                                                           (mb * 8 + q * 2) * wstep, AUX);
                 }
                 if (a.out_act) {
                     epi_v2u o;
@@ -219,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16
                         for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[j];
                         o = __builtin_bit_cast(epi_v2u, pk);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_act, vo_act, (mb * 4 + q) * wstep, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_act, vo_act, (mb * 4 + q) * wstep, AUX);
                 }
             }
         }

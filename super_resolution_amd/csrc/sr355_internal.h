@@ -68,6 +68,24 @@ struct DenseArgs {
     ConvArgs tail;                 // conv5's epilogue: residuals, carriers, outputs (cout 64); N/H/W set by the launcher
 };
 
+// One pass of the chain kernel (conv3x3_chain.hip): a conv restricted to one block of 32 output channels.
+struct ChainPass {
+    ConvArgs a;       // w and bias already point at the block; n_stages set; N/H/W/in_units as in ChainArgs
+    int cb_co;        // first output channel of the block
+    int need;         // passes that must be complete on the neighbouring tiles before stage dep_stage is requested
+    int dep_stage;    // first stage that reads the previous pass's output: n_stages = none, 0 = all, otherwise >= 2
+    int pad;
+};
+struct ChainArgs {
+    const ChainPass *passes;   // device memory, written before the launch
+    int n_passes;
+    unsigned *flags;           // one word per tile, zero at launch: passes complete on that tile
+    unsigned *err;             // raised when a wait gave up
+    int N, H, W, in_units;
+    int tiles_x, tiles_y;      // set by the launcher
+    unsigned long long *trace; // timing builds only (SR355_TRACE): eight words per workgroup, normally null
+};
+
 // Timing experiments (skip the loads / the stores of a conv) exist in builds with SR355_TRACE only (csrc/tools); the
 // library proper has no such switch.
 #ifdef SR355_TRACE
@@ -88,6 +106,11 @@ int launch_conv3x3_ring(const ConvArgs &a, int cin_units, int weight_split, hipS
 // Ring kernel with a branch-free, MFMA-interleaved stage body; n_stages, n_real_stages and debug must be set.
 int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream);
 int launch_conv3x3_fine_small(const ConvArgs &a, hipStream_t stream);
+
+// A chain of convs over one geometry as one persistent launch (large images).  `max_workgroups` > 0 caps the grid.
+bool chain_supported(const ConvArgs &a, int cin_units);
+int chain_resident_workgroups(int *out);
+int launch_conv3x3_chain(const ChainArgs &c, int max_workgroups, hipStream_t stream);
 
 // Fused dense block for images at most 32 pixels wide (bf16, 64 features, 32 growth channels).
 bool dense_block_supported(int nf, int gc, int dtype, int W);
