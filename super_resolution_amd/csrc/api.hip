@@ -1032,7 +1032,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         // timing builds: where wave 0 of every workgroup spent the launch (medians over the workgroups, microseconds)
         static unsigned long long *trace_dev = nullptr;
         if (getenv("SR355_CHAIN_TRACE")) {
-            if (!trace_dev && hipMalloc((void **)&trace_dev, 4096 * 64) != hipSuccess) trace_dev = nullptr;
+            if (!trace_dev && hipMalloc((void **)&trace_dev, 4096 * 96) != hipSuccess) trace_dev = nullptr;
             ca.trace = trace_dev;
         }
 #endif
@@ -1041,16 +1041,17 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         if (ca.trace) {
             static int calls = 0;
             if (++calls == 5) {
-                std::vector<unsigned long long> t(4096 * 8);
+                std::vector<unsigned long long> t(4096 * 12);
                 (void)hipStreamSynchronize(stream);
-                (void)hipMemcpy(t.data(), trace_dev, 4096 * 64, hipMemcpyDeviceToHost);
-                const char *names[8] = {"poll + acquire issue", "stage wait (DMA landed)", "stage barrier", "epilogue issue",
-                                        "restart (drain, publish, poll, acquire, first stage issue)", "acquire completion",
-                                        "first-stage wait of a pass (stores drain)", "total"};
+                (void)hipMemcpy(t.data(), trace_dev, 4096 * 96, hipMemcpyDeviceToHost);
+                const char *names[12] = {"poll + acquire issue", "stage wait (DMA landed)", "stage barrier", "epilogue issue",
+                                         "restart (drain, publish, poll, acquire, first stage issue)", "acquire completion",
+                                         "first-stage wait of a pass (stores drain)", "total", "cursor enters the next pass",
+                                         "descriptor fetch at the start of a pass", "", ""};
                 const int nwg = 512;
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < 10; ++k) {
                     std::vector<double> v;
-                    for (int b = 0; b < nwg; ++b) v.push_back(t[(size_t)b * 8 + k] * 0.01);
+                    for (int b = 0; b < nwg; ++b) v.push_back(t[(size_t)b * 12 + k] * 0.01);
                     std::sort(v.begin(), v.end());
                     fprintf(stderr, "chain trace: %-60s p10 %9.1f median %9.1f p90 %9.1f us\n", names[k], v[nwg / 10],
                             v[nwg / 2], v[nwg * 9 / 10]);

@@ -84,18 +84,26 @@ typedef ChainGeo G;
 //     counter: a load issued behind a store cannot be waited for without waiting for that store, and a write-through
 //     store takes microseconds.
 // A chain pass has no sign mask and no NCHW / uint8 output (chain_supported).
-// A 16-byte store reads its data registers over several cycles after it issues; a VALU write of one of them in the next
-// two cycles changes what the last lanes store.  The compiler pads that window inside a basic block, but here the
-// store ends a block (the outputs are optional) and the next row's arithmetic, which reuses the registers, begins the
-// following one: without the pad lanes 12-15 and 28-31 of each half-wave stored the next row's intermediate values.
-#define CHAIN_STORE_PAD() asm volatile("s_nop 1" ::: "memory")
+// A 16-byte write-through store reads its data registers for longer after it issues than the compiler allows for: with
+// the store builtin, arithmetic of the next quad that reused those registers three instructions later changed what
+// lanes 12-15 and 28-31 of each half-wave stored (measured; plain 16-byte stores and 8-byte write-through stores of
+// the other kernels do not show it).  The store therefore goes out as inline asm with 16 wait states (a quarter-wave
+// of four dwords per cycle) inside the same statement, where nothing can be scheduled between.
+typedef int chain_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void chain_store16(const epi_v4u &data, chain_v4i rsrc, int voffset, int soffset) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 15"
+                 :
+                 : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
+                 : "memory");
+}
 
-// FIRST: the first skip is absent (0), the bf16 activations (1) or an fp32 carrier (2); SECOND: a.res2 is present.
-// Compile-time, so that only the loads a pass has occupy registers.
-template <int FIRST, bool SECOND>
+// FIRST: the first skip is absent (0), the bf16 activations (1) or an fp32 carrier (2); SECOND: a.res2 is present;
+// OUTF32: the fp32 carrier a.out_f32 is written; F16: a.out_act is stored as fp16.  a.out_act always exists.
+// Compile-time, so that only the loads a pass has occupy registers and no quad branches on what the pass writes.
+template <int FIRST, bool SECOND, bool OUTF32, bool F16>
 __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&acc)[1][G::NB], const unsigned char *bias_lds,
                                                   int n, int y0, int x, int cb_co, int h) {
-    constexpr int NB = G::NB, AUX = 16;
+    constexpr int NB = G::NB;
     const int H = a.H, W = a.W;
     const int wstep = __builtin_amdgcn_readfirstlane(W * 16);          // bytes from one unit of a row to the next
     auto rsrc = [&](const void *base, size_t img_bytes) {
@@ -106,11 +114,20 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
             0, __builtin_amdgcn_readfirstlane((int)img_bytes), 0x00020000);
     };
     const size_t f32_img = (size_t)H * W * a.f32_units * 16;
-    const __amdgpu_buffer_rsrc_t rs_act = rsrc(a.out_act, (size_t)H * W * a.out_units * 16);
+    auto rsrc_words = [&](const void *base, size_t img_bytes) {     // the same descriptor as four scalar words
+        const unsigned long long p = (unsigned long long)base + (size_t)n * img_bytes;
+        chain_v4i w;
+        w[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+        w[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) & 0xffff;
+        w[2] = __builtin_amdgcn_readfirstlane((int)img_bytes);
+        w[3] = 0x00020000;
+        return w;
+    };
+    const chain_v4i rw_act = rsrc_words(a.out_act, (size_t)H * W * a.out_units * 16);
     const __amdgpu_buffer_rsrc_t rs_ra = rsrc(a.res_act, (size_t)H * W * a.res_act_units * 16);
     const __amdgpu_buffer_rsrc_t rs_r1 = rsrc(a.res1, f32_img);
     const __amdgpu_buffer_rsrc_t rs_r2 = rsrc(a.res2, f32_img);
-    const __amdgpu_buffer_rsrc_t rs_f32 = rsrc(a.out_f32, f32_img);
+    const chain_v4i rw_f32 = rsrc_words(a.out_f32, f32_img);
     const float slope = a.slope;
     constexpr bool has_ra = FIRST == 1, has_r1 = FIRST == 2, has_r2 = SECOND;
     int vo_act16[NB], vo_ra[NB], vo_f[NB];
@@ -122,9 +139,21 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
         vo_ra[nb] = ok ? ((y * a.res_act_units + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
         vo_f[nb] = ok ? ((y * a.f32_units + (cb_co >> 2) + h) * W + x) * 16 : OOB;
     }
+    // The bias image landed stages ago (its DMA was issued when the cursor entered this pass).  Read through inline asm:
+    // the compiler puts a wait for ALL outstanding DMA (s_waitcnt vmcnt(0)) in front of any LDS read it can see, which
+    // here would stall the epilogue on the next pass's first stage, requested a moment ago.
     float4 bv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4 *>(bias_lds + (q * 8 + h * 4) * 4);
+    {
+        const unsigned b = (unsigned)(size_t)(bias_lds + h * 16);
+        epi_v4f t0, t1, t2, t3;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                     "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(b)
+                     : "memory");
+        bv[0] = make_float4(t0[0], t0[1], t0[2], t0[3]), bv[1] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        bv[2] = make_float4(t2[0], t2[1], t2[2], t2[3]), bv[3] = make_float4(t3[0], t3[1], t3[2], t3[3]);
+    }
     // Rows are handled in groups whose skip loads fit the register file beside the accumulators: all four rows at
     // once, or two and two when both skips are present (the second group's loads then wait for the first group's
     // stores: one write-through round trip per pass instead of one per row).
@@ -178,15 +207,13 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = epi_axpby(a.res2_w, rf[j], a.res2_scale, v[j]);
                 }
-                if (a.out_f32) {
+                if constexpr (OUTF32) {
                     const epi_v4f of = {v[0], v[1], v[2], v[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_f32, vo_f[nb], q * 2 * wstep,
-                                                           AUX);
-                    CHAIN_STORE_PAD();
+                    chain_store16(__builtin_bit_cast(epi_v4u, of), rw_f32, vo_f[nb], q * 2 * wstep);
                 }
-                if (a.out_act) {
+                {
                     epi_v2u o;
-                    if (a.f16_out) {
+                    if constexpr (F16) {
                         epi_f16x4 pk;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
@@ -203,8 +230,7 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
                         const auto s0 = __builtin_amdgcn_permlane32_swap(o_even[0], o[0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(o_even[1], o[1], false, false);
                         const epi_v4u unit = {s0[0], s1[0], s0[1], s1[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(unit, rs_act, vo_act16[nb], (q - 1) * wstep, AUX);
-                        CHAIN_STORE_PAD();
+                        chain_store16(unit, rw_act, vo_act16[nb], (q - 1) * wstep);
                     }
                 }
             }
@@ -214,16 +240,21 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
 
 __device__ __forceinline__ void chain_epilogue(const ConvArgs &a, f32x16 (&acc)[1][G::NB], const unsigned char *bias_lds,
                                                int n, int y0, int x, int cb_co, int h) {
+    // the combinations the generator's body has; anything else takes the shared tile epilogue
     const int first = a.res_act ? 1 : (a.res1 ? 2 : 0);
-    if (!a.res2) {
-        if (first == 0) chain_epilogue_as<0, false>(a, acc, bias_lds, n, y0, x, cb_co, h);
-        else if (first == 1) chain_epilogue_as<1, false>(a, acc, bias_lds, n, y0, x, cb_co, h);
-        else chain_epilogue_as<2, false>(a, acc, bias_lds, n, y0, x, cb_co, h);
-    } else {
-        if (first == 0) chain_epilogue_as<0, true>(a, acc, bias_lds, n, y0, x, cb_co, h);
-        else if (first == 1) chain_epilogue_as<1, true>(a, acc, bias_lds, n, y0, x, cb_co, h);
-        else chain_epilogue_as<2, true>(a, acc, bias_lds, n, y0, x, cb_co, h);
-    }
+    const bool second = a.res2 != nullptr, outf32 = a.out_f32 != nullptr, f16 = a.f16_out != 0;
+#define CHAIN_EPI(FI, SE, OF, FH)                                                                     \
+    if (first == FI && second == SE && outf32 == OF && f16 == FH)                                     \
+        return chain_epilogue_as<FI, SE, OF, FH>(a, acc, bias_lds, n, y0, x, cb_co, h)
+    CHAIN_EPI(0, false, false, false);   // growth convs
+    CHAIN_EPI(1, false, false, false);   // conv5, dense skip from the bf16 activations
+    CHAIN_EPI(1, true, true, false);     // conv5 of an RRDB's last block: + RRDB skip, fp32 carrier out
+    CHAIN_EPI(2, false, true, false);    // conv5, every skip on an fp32 carrier
+    CHAIN_EPI(2, true, true, false);
+    CHAIN_EPI(2, false, false, false);   // trunk_conv + global skip
+    CHAIN_EPI(2, false, false, true);    // the same, feeding an fp16 conv
+#undef CHAIN_EPI
+    conv_epilogue_tile<1, G::NB, 16>(a, acc, bias_lds, n, y0, x, cb_co, h, true);
 }
 }  // namespace
 
@@ -372,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
 
     bool gave_up = false;
 #ifdef SR355_TRACE
-    unsigned long long tr_[8] = {};
+    unsigned long long tr_[12] = {};
     const unsigned long long tr_start_ = wall_clock64();
 #endif
     f32x16 acc[1][NB];
@@ -442,7 +473,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
                 ct_i = i;
             }
         }
-        const int S = passes[p].a.n_stages;
+        // the pass descriptor, fetched now: its scalar-cache misses hide behind the stages
+        CHAIN_T0(td_);
+        ConvArgs a;
+        {
+            typedef __attribute__((address_space(4))) const unsigned cword_t;
+            cword_t *src = (cword_t *)&passes[p].a;
+            static_assert(sizeof(ConvArgs) % 4 == 0, "descriptor is whole words");
+            unsigned words[sizeof(ConvArgs) / 4];
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(ConvArgs) / 4; ++i) words[i] = src[i];
+            __builtin_memcpy(&a, words, sizeof(a));     // (not a cast: the fields are floats and pointers)
+        }
+        const int cb_co = passes[p].cb_co;
+        const int S = a.n_stages;
+        CHAIN_ADD(9, td_);
         for (int s = 0; s < S; ++s) {
             // the stage the cursor requests in this iteration is the first one that reads the previous pass's output
             // on other tiles: wait for the neighbours and acquire before the boundary below
@@ -491,25 +536,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             slot ^= 1;
             // advance the cursor (branches, kept out of the MFMA blocks)
             if (live && ++it_stage == it_S) {
+                CHAIN_T0(ta_);
                 it_stage = 0;
                 if (++it_ord < n_ord) SR355_TASK_SETUP(it_ord);
+                CHAIN_ADD(8, ta_);
             }
         }
         // ---- epilogue of task ord: write-through stores, published at the next stage boundary ----
         CHAIN_T0(te_);
         {
-            ConvArgs a;       // the descriptor, word by word through the scalar cache
-            {
-                typedef __attribute__((address_space(4))) const unsigned cword_t;
-                cword_t *src = (cword_t *)&passes[p].a;
-                static_assert(sizeof(ConvArgs) % 4 == 0, "descriptor is whole words");
-                unsigned words[sizeof(ConvArgs) / 4];
-#pragma unroll
-                for (unsigned i = 0; i < sizeof(ConvArgs) / 4; ++i) words[i] = src[i];
-                __builtin_memcpy(&a, words, sizeof(a));     // (not a cast: the fields are floats and pointers)
-            }
             chain_epilogue(a, acc, smem + G::BIAS_OFF + (ord & 1) * 256, ct_n, ct_ty * G::TH + wave * NB, ct_tx * 32 + r,
-                           passes[p].cb_co, h);
+                           cb_co, h);
         }
         CHAIN_ADD(3, te_);
         pub_tile = (ct_n * c.tiles_y + ct_ty) * c.tiles_x + ct_tx;
@@ -535,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
 #ifdef SR355_TRACE
     if (c.trace && tid == 0) {
         tr_[7] = wall_clock64() - tr_start_;
-        for (int k = 0; k < 8; ++k) c.trace[blockIdx.x * 8 + k] = tr_[k];
+        for (int k = 0; k < 12; ++k) c.trace[blockIdx.x * 12 + k] = tr_[k];
     }
 #endif
 #undef SR355_RSRC
@@ -581,7 +618,7 @@ int chain_resident_workgroups(int *out) {
 
 bool chain_supported(const ConvArgs &a, int cin_units) {
     return a.ups == 0 && a.zins == 0 && !a.f16_in && a.stride != 2 && (cin_units % RSU) == 0 && cin_units >= 2 * RSU &&
-           (a.cout_pad == 32 || a.cout_pad == 64) && a.cout_real == a.cout_pad && !a.out_nchw && !a.out_u8;
+           (a.cout_pad == 32 || a.cout_pad == 64) && a.cout_real == a.cout_pad && !a.out_nchw && !a.out_u8 && a.out_act && !a.mask_act;
 }
 
 int launch_conv3x3_chain(const ChainArgs &c0, int max_workgroups, hipStream_t stream) {

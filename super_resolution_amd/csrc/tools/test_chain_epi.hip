@@ -17,9 +17,9 @@ __global__ __launch_bounds__(256) void epi_kernel(ConvArgs a, const float *accs,
     for (int nb = 0; nb < 4; ++nb)
         for (int e = 0; e < 16; ++e) acc[0][nb][e] = accs[((wave * 4 + nb) * 64 + lane) * 16 + e];
     if (variant == 0) conv_epilogue_tile<1, 4, 16>(a, acc, bias_lds, 0, wave * 4, r, 0, h, true);
-    else if (MODE == 0) chain_epilogue_as<1, false>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
-    else if (MODE == 1) chain_epilogue_as<1, true>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
-    else chain_epilogue_as<2, true>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
+    else if (MODE == 0) chain_epilogue_as<1, false, false, false>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
+    else if (MODE == 1) chain_epilogue_as<1, true, true, false>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
+    else chain_epilogue_as<2, true, true, false>(a, acc, bias_lds, 0, wave * 4, r, 0, h);
 }
 
 int main() {
