@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 10
+#define SR355_ABI_VERSION 11
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -302,6 +302,15 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
                                size_t packed_bytes, const unsigned char *in_u8hwc_dev,
                                unsigned char *out_u8hwc_dev, int N, int H, int W, void *workspace_dev,
                                size_t workspace_bytes, void *stream);
+
+/* Measurement hook for the persistent launch that runs the body of sr355_generator_forward / _forward_u8 (every dense
+ * block and trunk_conv as one kernel, taken for batches / images of at least 128 tiles of 16 x 32 LR pixels; the
+ * module of /root/reference/esrgan/models/esrgan_model.py:55-58 has no counterpart: there every conv is a launch).
+ * sr355_chain_timing(1) makes the following forwards record a HIP event on the launch stream right before and right
+ * after that kernel; sr355_chain_last_ms() waits for the later event of the most recent such forward on the current
+ * device and returns the kernel's duration in milliseconds (a negative value if none was recorded). */
+void sr355_chain_timing(int on);
+float sr355_chain_last_ms(void);
 
 /* One Adam update over flat fp32 device buffers of n elements, in one launch: the arithmetic of
  * torch.optim.Adam(lr, betas) as the reference configures it (/root/reference/esrgan/train.py:117-122; no amsgrad,

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -785,6 +786,23 @@ static unsigned *chain_err_host(int dev) {
     return word[dev];
 }
 
+// Optional events around the chain launch (sr355_chain_timing / sr355_chain_last_ms).
+static std::atomic<int> g_chain_timing{0};
+struct ChainEvents {
+    hipEvent_t before = nullptr, after = nullptr;
+    bool recorded = false;
+};
+static ChainEvents *chain_events(int dev) {
+    static std::once_flag once[64];
+    static ChainEvents ev[64];
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::call_once(once[dev], [dev] {
+        if (hipEventCreate(&ev[dev].before) != hipSuccess || hipEventCreate(&ev[dev].after) != hipSuccess)
+            ev[dev].before = ev[dev].after = nullptr;
+    });
+    return ev[dev].before ? &ev[dev] : nullptr;
+}
+
 // Input: fp32 NCHW, or (in_u8) a uint8 HWC image batch read as byte / 255.  Output: fp32 NCHW unclamped, or (out_u8)
 // the uint8 HWC image batch the reference's inference saves (clamp, mul 255, truncate).
 static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpec> &specs, const unsigned char *pk,
@@ -983,8 +1001,10 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         // The collected convs as passes of 32 output channels.  A pass's `need` is its own index: everything before it.
         chain_collect = false;
         std::vector<ChainPass> passes;
+        int prev_blocks = 0, prev_cout = 0;       // output-channel blocks (= passes) and channels of the conv before
         for (const ChainConv &cc : chain_convs) {
             const int S = cc.cin_units / 2;
+            const int first_pass = (int)passes.size();
             for (int cb = 0; cb < cc.a.cout_pad / 32; ++cb) {
                 ChainPass ps;
                 memset(&ps, 0, sizeof(ps));
@@ -993,16 +1013,26 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                 ps.a.w = cc.a.w + (size_t)cb * 32 * 16;
                 ps.a.bias = cc.a.bias + cb * 32;
                 ps.cb_co = cb * 32;
-                ps.need = (int)passes.size();
+                ps.need = first_pass;
                 // the second block of output channels reads what the first one read: nothing new to wait for
                 ps.dep_stage = cb ? S : (cc.all_stages ? 0 : S - 2);
-                if (passes.empty()) ps.dep_stage = S;      // the chain's input comes from the launch before it
+                if (cb == 0 && cc.all_stages && prev_blocks == 2 && cc.cin_units * 8 == prev_cout && S == 4) {
+                    // The whole input was written by the two passes of the conv before: stages 0, 1 read the first
+                    // pass's 32 channels, stages 2, 3 the second's.  The first stage can then be requested while this
+                    // workgroup still computes that second pass, and the pipeline does not restart.
+                    ps.need = first_pass - 1;
+                    ps.dep2_stage = 2;
+                    ps.need2 = first_pass;
+                }
+                if (first_pass == 0) ps.dep_stage = S, ps.need2 = 0;      // the chain's input comes from the launch before it
                 if (ps.dep_stage == 1 || S < 2) {
                     set_error("generator forward: chain pass with %d stages cannot be ordered", S);
                     return SR355_ERR_UNSUPPORTED;
                 }
                 passes.push_back(ps);
             }
+            prev_blocks = cc.a.cout_pad / 32;
+            prev_cout = cc.a.cout_pad;
         }
         if (passes.size() * sizeof(ChainPass) > (size_t)(18 * cfg->num_blocks + 2) * sizeof(ChainPass)) {
             set_error("generator forward: chain table overflow");
@@ -1036,7 +1066,13 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             ca.trace = trace_dev;
         }
 #endif
+        ChainEvents *cev = g_chain_timing.load() ? chain_events(dev) : nullptr;
+        if (cev && check_hip(hipEventRecord(cev->before, stream), "hipEventRecord")) return SR355_ERR_HIP;
         if ((rc = launch_conv3x3_chain(ca, 0, stream))) return rc;
+        if (cev) {
+            if (check_hip(hipEventRecord(cev->after, stream), "hipEventRecord")) return SR355_ERR_HIP;
+            cev->recorded = true;
+        }
 #ifdef SR355_TRACE
         if (ca.trace) {
             static int calls = 0;
@@ -1154,6 +1190,19 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
     fb.chain_table = (ChainPass *)(wsb + ws.chain_table);
     return run_forward(cfg, specs, (const unsigned char *)packed, nullptr, nullptr, N, H, W, ws, fb,
                        (hipStream_t)stream_, in_u8hwc, out_u8hwc);
+}
+
+void sr355_chain_timing(int on) { g_chain_timing.store(on ? 1 : 0); }
+
+float sr355_chain_last_ms(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1.f;
+    ChainEvents *cev = chain_events(dev);
+    if (!cev || !cev->recorded) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(cev->after) != hipSuccess || hipEventElapsedTime(&ms, cev->before, cev->after) != hipSuccess)
+        return -1.f;
+    return ms;
 }
 
 int sr355_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,

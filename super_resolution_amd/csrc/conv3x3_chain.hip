@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     int voff[G::KMAX];
     int in_lo = 0, in_hi = 0, w_lo = 0, w_hi = 0, w_len = 0, w_stage_stride = 0;
     const int in_len = __builtin_amdgcn_readfirstlane(img_bytes);
-    int it_ord = 0, it_stage = 0, it_S = 0, it_dep = 0, it_need = 0;
+    int it_ord = 0, it_stage = 0, it_S = 0, it_dep = 0, it_need = 0, it_dep2 = 0, it_need2 = 0, it_p = 0;
     int it_tx = 0, it_ty = 0, it_n = 0, it_i = -1;
 
     // Set the cursor up for task ORD: descriptor of its pass, tile coordinates, per-lane source offsets, bias image.
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         const int i_ = (ORD)-p_ * n_my;                                                               \
         cpass_t *d_ = passes + p_;                                                                    \
         it_S = d_->a.n_stages, it_dep = d_->dep_stage, it_need = d_->need;                            \
+        it_dep2 = d_->dep2_stage, it_need2 = d_->need2, it_p = p_;                                    \
         const int cout_pad_ = d_->a.cout_pad;                                                         \
         w_stage_stride = RSU * 9 * cout_pad_ * 16;                                                    \
         const unsigned long long wb_ = (unsigned long long)(d_->a.w);                                 \
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         }                                                                                             \
     }
 
-    // Wave 0 waits until `it_need` passes are complete on the neighbours of the cursor's tile, then acquires.
-#define SR355_AWAIT_NEIGHBOURS()                                                                      \
+    // Wave 0 waits until NEED passes are complete on the neighbours of the cursor's tile, then acquires.
+#define SR355_AWAIT_NEIGHBOURS(NEED)                                                                  \
     if (wave == 0) {                                                                                  \
         const int dy_ = lane / 3 - 1, dx_ = lane % 3 - 1;                                             \
         const int ty_ = it_ty + dy_, tx_ = it_tx + dx_;                                               \
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         const unsigned long long t0_ = wall_clock64();                                                \
         while (!gave_up) {                                                                            \
             const unsigned v_ = polls_ ? __hip_atomic_load(f_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; \
-            if (__all(!polls_ || v_ >= (unsigned)it_need)) break;                                     \
+            if (__all(!polls_ || v_ >= (unsigned)(NEED))) break;                                      \
             __builtin_amdgcn_s_sleep(2);                                                              \
             if (wall_clock64() - t0_ > 200000000ull) {   /* 2 s at 100 MHz: a peer is not resident */ \
                 if (lane == 0) __hip_atomic_store((gu32 *)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
@@ -442,14 +443,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         }                                                                                             \
     }
 
-    // A cursor that stands in front of a pass whose every stage depends on the previous pass (a block's first conv)
-    // cannot run ahead of this workgroup's own epilogue: it is held there and restarted after the epilogue.
-#define SR355_CURSOR_HELD() (it_ord < n_ord && it_stage == 0 && it_dep == 0 && it_need > 0)
+    // A cursor that stands in front of a pass whose first stage needs the pass this workgroup is still computing
+    // cannot run ahead of the workgroup's own epilogue: it is held there and restarted after the epilogue.
+#define SR355_CURSOR_HELD(CUR_P) (it_ord < n_ord && it_stage == 0 && it_dep == 0 && it_need > (CUR_P))
 
     // ---- prologue: first task, first stage ----
     SR355_TASK_SETUP(0);
-    if (SR355_CURSOR_HELD()) {   // (a chain whose first pass reads another launch's output has need = 0)
-        SR355_AWAIT_NEIGHBOURS();
+    if (SR355_CURSOR_HELD(-1) && it_need > 0) {   // (a chain whose first pass reads another launch's output has need = 0)
+        SR355_AWAIT_NEIGHBOURS(it_need);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -491,10 +492,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         for (int s = 0; s < S; ++s) {
             // the stage the cursor requests in this iteration is the first one that reads the previous pass's output
             // on other tiles: wait for the neighbours and acquire before the boundary below
-            const bool live = it_ord < n_ord && !SR355_CURSOR_HELD();
-            if (live && it_stage == it_dep && it_need > 0) {
+            const bool live = it_ord < n_ord && !SR355_CURSOR_HELD(p);
+            const bool dep1 = it_stage == it_dep && it_need > 0, dep2 = it_stage == it_dep2 && it_need2 > 0;
+            if (live && (dep1 || dep2)) {
                 CHAIN_T0(tp_);
-                SR355_AWAIT_NEIGHBOURS();
+                const int need_now = dep2 ? it_need2 : it_need;
+                SR355_AWAIT_NEIGHBOURS(need_now);
                 CHAIN_ADD(0, tp_);
                 CHAIN_T0(tq_);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         CHAIN_ADD(3, te_);
         pub_tile = (ct_n * c.tiles_y + ct_ty) * c.tiles_x + ct_tx;
         pub_val = (unsigned)(p + 1);
-        if (SR355_CURSOR_HELD() && it_ord == ord + 1) {
+        if (SR355_CURSOR_HELD(p) && it_ord == ord + 1) {
             CHAIN_T0(tr0_);
             // restart: publish this pass, wait for the neighbours, then request the next pass's first stage
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             if (tid == 0)
                 __hip_atomic_store((gu32 *)c.flags + pub_tile, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub_tile = -1;
-            SR355_AWAIT_NEIGHBOURS();
+            SR355_AWAIT_NEIGHBOURS(it_need);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             SR355_ISSUE_DMA(slot, true);      // the slot the next iteration reads

@@ -73,8 +73,10 @@ struct ChainPass {
     ConvArgs a;       // w and bias already point at the block; n_stages set; N/H/W/in_units as in ChainArgs
     int cb_co;        // first output channel of the block
     int need;         // passes that must be complete on the neighbouring tiles before stage dep_stage is requested
-    int dep_stage;    // first stage that reads the previous pass's output: n_stages = none, 0 = all, otherwise >= 2
-    int pad;
+    int dep_stage;    // first stage that reads the previous conv's output: n_stages = none, 0 = all, otherwise >= 2
+    int need2;        // a second such point (a conv whose input was written by two passes: the first one's channels are
+    int dep2_stage;   // needed from stage 0, the second one's from dep2_stage >= 2); need2 = 0: none
+    int pad[3];
 };
 struct ChainArgs {
     const ChainPass *passes;   // device memory, written before the launch
