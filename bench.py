@@ -135,7 +135,7 @@ def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=Tru
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02g_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -175,10 +175,9 @@ def chain_roofline(net, x, rows, forwards=10):
     return {"bound": "mfma", "kernel": "conv3x3_chain (the 345 body convs + trunk_conv as one persistent launch)",
             "achieved": round(flop / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "traffic": None,
-            "traffic_source": "not collected for this kernel (the PMC summary under profiles/ covers the per-conv kernels "
-                              "it replaces: their 2 x FETCH_SIZE + WRITE_SIZE per launch is listed under "
-                              "roofline_other_kernels)",
+            "traffic": measured_traffic("conv3x3_chain"),
+            "traffic_source": "profiles/r02g_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
+                              "rocprofv3 --pmc passes over this command; the committed summary, not a live reading)",
             "avg_launch_us": round(sec * 1e6, 1), "launches_per_forward": 1, "flop_per_launch": flop,
             "algorithmic_bytes_per_launch": round(nbytes),
             "hbm_side": {"achieved": round(nbytes / sec / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -211,8 +210,8 @@ def roofline_from(rows):
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r01k_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, PMC passes "
-                              "of this command with --streams 1)",
+            "traffic_source": "profiles/r02g_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
+                              "rocprofv3 --pmc passes; the committed summary, not a live reading)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),
             # the same launch against the memory roof: below the ridge (peak FLOP/s / peak B/s) the algorithmic bytes,
@@ -539,6 +538,10 @@ def main():
     # rehearsal of the multi-rank path on a one-GPU box: SR355_BENCH_REHEARSAL=1 puts every rank on device 0 and
     # uses gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
     rehearsal = world > 1 and os.environ.get("SR355_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        # ranks share one GPU here: the body's persistent launch needs all its workgroups resident, which two
+        # processes on one device cannot both have
+        os.environ["SR355_CHAIN"] = "0"
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -620,7 +623,9 @@ def main():
     if not args.no_extras:
         try:
             if world > 1:
+                print(f"[bench rank {rank}] strong scaling", file=sys.stderr, flush=True)
                 line["strong_scaling"] = strong_scaling(net, dev, world, dist, B, H, W, max(5, args.steps // 2))
+                print(f"[bench rank {rank}] other configurations", file=sys.stderr, flush=True)
             extras = other_configs(net, dev, world, rank, dist)
             if rank == 0:
                 line["other_configs"] = extras

@@ -786,6 +786,25 @@ static unsigned *chain_err_host(int dev) {
     return word[dev];
 }
 
+// Two chain kernels in flight on one GPU could each hold part of the workgroup slots and wait for peers that never
+// become resident.  Within a process they are therefore serialised: every chain launch waits for the event recorded
+// behind the previous one (a no-op on the same stream).  Another PROCESS running the same kernel on the same GPU is
+// not covered: its waits would give up after two seconds and the next call reports it.
+struct ChainOrder {
+    std::mutex m;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+};
+static ChainOrder *chain_order(int dev) {
+    static std::once_flag once[64];
+    static ChainOrder ord[64];
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::call_once(once[dev], [dev] {
+        if (hipEventCreateWithFlags(&ord[dev].done, hipEventDisableTiming) != hipSuccess) ord[dev].done = nullptr;
+    });
+    return ord[dev].done ? &ord[dev] : nullptr;
+}
+
 // Optional events around the chain launch (sr355_chain_timing / sr355_chain_last_ms).
 static std::atomic<int> g_chain_timing{0};
 struct ChainEvents {
@@ -1066,12 +1085,24 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             ca.trace = trace_dev;
         }
 #endif
+        ChainOrder *order = chain_order(dev);
+        if (!order) {
+            set_error("generator forward: cannot create the event that orders chain launches");
+            return SR355_ERR_HIP;
+        }
         ChainEvents *cev = g_chain_timing.load() ? chain_events(dev) : nullptr;
-        if (cev && check_hip(hipEventRecord(cev->before, stream), "hipEventRecord")) return SR355_ERR_HIP;
-        if ((rc = launch_conv3x3_chain(ca, 0, stream))) return rc;
-        if (cev) {
-            if (check_hip(hipEventRecord(cev->after, stream), "hipEventRecord")) return SR355_ERR_HIP;
-            cev->recorded = true;
+        {
+            std::lock_guard<std::mutex> lock(order->m);
+            if (order->recorded && check_hip(hipStreamWaitEvent(stream, order->done, 0), "hipStreamWaitEvent"))
+                return SR355_ERR_HIP;
+            if (cev && check_hip(hipEventRecord(cev->before, stream), "hipEventRecord")) return SR355_ERR_HIP;
+            if ((rc = launch_conv3x3_chain(ca, 0, stream))) return rc;
+            if (cev) {
+                if (check_hip(hipEventRecord(cev->after, stream), "hipEventRecord")) return SR355_ERR_HIP;
+                cev->recorded = true;
+            }
+            if (check_hip(hipEventRecord(order->done, stream), "hipEventRecord")) return SR355_ERR_HIP;
+            order->recorded = true;
         }
 #ifdef SR355_TRACE
         if (ca.trace) {

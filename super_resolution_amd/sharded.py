@@ -57,9 +57,14 @@ def sharded_forward(net: Callable[[Tensor], Tensor], x: Tensor, halo: int = 16, 
     if rank < len(edges):
         mine = run_band(net, x, edges[rank], scale)
         padded[:, :, : mine.shape[2]] = mine
-    bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bucket, dst=dst, group=group)
+    # RCCL gathers device tensors; on gloo (tests, CPU-only fabrics) a device tensor is staged through host memory
+    # (gloo's own device-tensor collectives stall when ranks share a GPU)
+    staged = padded.is_cuda and dist.get_backend(group) != "nccl"
+    send = padded.cpu() if staged else padded
+    bucket = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bucket, dst=dst, group=group)
     if rank != dst:
         return None
     parts = [bucket[i][:, :, : scale * (e[1] - e[0])] for i, e in enumerate(edges)]
-    return torch.cat(parts, dim=2)
+    out = torch.cat(parts, dim=2)
+    return out.to(x.device) if staged else out
