@@ -17,6 +17,8 @@
 
 #include <mutex>
 
+#include <atomic>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -522,17 +524,17 @@ size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
 }
 
 static int wgrad_set_attr(int mbi) {
-    static bool attr_done[2][64] = {};
+    static std::atomic<bool> attr_done[2][64];      // (zero-initialised; acquire / release: threads may race here)
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
     if (dev < 0 || dev >= 64) dev = 0;
-    if (!attr_done[mbi][dev]) {
+    if (!attr_done[mbi][dev].load(std::memory_order_acquire)) {
         hipError_t e = mbi ? hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb2),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<2>::LDS_BYTES)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb1),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<1>::LDS_BYTES);
         if (check_hip(e, "hipFuncSetAttribute")) return SR355_ERR_HIP;
-        attr_done[mbi][dev] = true;
+        attr_done[mbi][dev].store(true, std::memory_order_release);
     }
     return SR355_OK;
 }
@@ -626,18 +628,18 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     a.dy_s2 = dy_stride2 ? 1 : 0;
     a.tiles_x = (W + 31) / 32;
     a.tiles_y = (H + WTH - 1) / WTH;
-    static bool attr_done[2][64] = {};
+    static std::atomic<bool> attr_done[2][64];      // (zero-initialised; acquire / release: threads may race here)
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
     if (dev < 0 || dev >= 64) dev = 0;
     const int mbi = co_pad == 64 ? 1 : 0;
-    if (!attr_done[mbi][dev]) {
+    if (!attr_done[mbi][dev].load(std::memory_order_acquire)) {
         hipError_t e = mbi ? hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb2),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<2>::LDS_BYTES)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3x3_kernel_mb1),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WGeo<1>::LDS_BYTES);
         if (check_hip(e, "hipFuncSetAttribute")) return SR355_ERR_HIP;
-        attr_done[mbi][dev] = true;
+        attr_done[mbi][dev].store(true, std::memory_order_release);
     }
     dim3 grid(G, chunks, 1);
     if (mbi)

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
+#include <atomic>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -263,15 +265,15 @@ static int launch_inst(const ConvArgs &a0, hipStream_t stream) {
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     auto kern = conv3x3_mfma<T, MB, NB, SU, ST>;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];         // (zero-initialised; acquire / release: threads may race here)
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    if (dev >= 0 && dev < 64 && !attr_done[dev].load(std::memory_order_acquire)) {
         if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                       "hipFuncSetAttribute"))
             return SR355_ERR_HIP;
-        attr_done[dev] = true;
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const long long nblk = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {

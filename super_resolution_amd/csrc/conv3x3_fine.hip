@@ -16,6 +16,8 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
+#include <atomic>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -379,12 +381,12 @@ static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     auto kern = conv3x3_fine<MB, NB, R, WPS, F16>;
-    static bool attr_done[64] = {};
-    static int n_cu[64] = {};
+    static std::atomic<bool> attr_done[64];         // (zero-initialised; acquire / release: threads may race here)
+    static std::atomic<int> n_cu[64];
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
     if (dev < 0 || dev >= 64) dev = 0;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                       "hipFuncSetAttribute"))
@@ -393,8 +395,8 @@ static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
         if (check_hip(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev),
                       "hipDeviceGetAttribute"))
             return SR355_ERR_HIP;
-        n_cu[dev] = cu > 0 ? cu : 256;
-        attr_done[dev] = true;
+        n_cu[dev].store(cu > 0 ? cu : 256, std::memory_order_relaxed);
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const long long n_tiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) {
@@ -404,7 +406,7 @@ static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     int wg_per_cu = (160 * 1024) / G::LDS_BYTES;
     if (wg_per_cu > WPS) wg_per_cu = WPS;
     if (wg_per_cu < 1) wg_per_cu = 1;
-    const long long slots = (long long)n_cu[dev] * wg_per_cu;
+    const long long slots = (long long)n_cu[dev].load(std::memory_order_relaxed) * wg_per_cu;
     dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots), a.cout_pad / G::CO, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, stream, a);
     return check_hip(hipGetLastError(), "conv3x3 fine launch");
@@ -424,17 +426,17 @@ int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     // 32 output channels: a wave's MFMA run per stage is short, and the barrier plus the first fragment reads of
     // every stage are exposed; 16-row tiles double the run (and halve the weight traffic per pixel) wherever they
     // still give every CU a tile
-    static int cu_of[64] = {};
+    static std::atomic<int> cu_of[64];
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
     if (dev < 0 || dev >= 64) dev = 0;
-    if (!cu_of[dev]) {
+    if (!cu_of[dev].load(std::memory_order_acquire)) {
         int n = 0;
         if (check_hip(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute"))
             return SR355_ERR_HIP;
-        cu_of[dev] = n > 0 ? n : 256;
+        cu_of[dev].store(n > 0 ? n : 256, std::memory_order_release);
     }
-    const int cu = cu_of[dev];
+    const int cu = cu_of[dev].load(std::memory_order_acquire);
     const long long tiles16 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
     static const int force_nb = [] { const char *e = getenv("SR355_NARROW_NB"); return e ? atoi(e) : 0; }();
     if (force_nb == 4 || (force_nb == 0 && tiles16 >= cu)) return launch_fine_inst<1, 4, 2>(b, stream);

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
+#include <atomic>
+
 #include "sr355_internal.h"
 
 namespace sr355 {
@@ -288,12 +290,12 @@ static int launch_ring_inst(const ConvArgs &a0, hipStream_t stream) {
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     auto kern = conv3x3_ring<MB, NB, WAVES, R, WPS>;
-    static bool attr_done[64] = {};
-    static int n_cu[64] = {};
+    static std::atomic<bool> attr_done[64];         // (zero-initialised; acquire / release: threads may race here)
+    static std::atomic<int> n_cu[64];
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
     if (dev < 0 || dev >= 64) dev = 0;
-    if (!attr_done[dev]) {
+    if (!attr_done[dev].load(std::memory_order_acquire)) {
         if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                       "hipFuncSetAttribute"))
@@ -302,8 +304,8 @@ static int launch_ring_inst(const ConvArgs &a0, hipStream_t stream) {
         if (check_hip(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev),
                       "hipDeviceGetAttribute"))
             return SR355_ERR_HIP;
-        n_cu[dev] = cu > 0 ? cu : 256;
-        attr_done[dev] = true;
+        n_cu[dev].store(cu > 0 ? cu : 256, std::memory_order_relaxed);
+        attr_done[dev].store(true, std::memory_order_release);
     }
     const long long n_tiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (n_tiles <= 0 || n_tiles > 0x7fffffffLL) {
@@ -314,7 +316,7 @@ static int launch_ring_inst(const ConvArgs &a0, hipStream_t stream) {
     const int by_waves = WPS * 4 / WAVES;   // register budget
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
     if (wg_per_cu < 1) wg_per_cu = 1;
-    const long long slots = (long long)n_cu[dev] * wg_per_cu;
+    const long long slots = (long long)n_cu[dev].load(std::memory_order_relaxed) * wg_per_cu;
     dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots), a.cout_pad / G::CO, 1);
     hipLaunchKernelGGL(kern, grid, dim3(G::THREADS), G::LDS_BYTES, stream, a);
     return check_hip(hipGetLastError(), "conv3x3 ring launch");

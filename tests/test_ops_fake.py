@@ -14,7 +14,8 @@ N, H, W = 2, 9, 33
 
 OPS = ("to_blocked", "from_blocked", "pack_weight", "conv3x3_fwd", "pack_weight_transposed", "pool2x2_sum",
        "conv3x3_wgrad", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
-       "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step")
+       "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step", "dense_block_fwd",
+       "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd")
 
 
 def test_every_op_is_registered_with_a_fake():
@@ -81,3 +82,18 @@ def test_generator_ops_under_fake_mode():
             assert gin.shape == ((N, 3, H, W) if need_x else (0,))
         p = cuda(n_params)
         assert torch.ops.sr355.adam_step(p, p, p, p, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1) is None
+
+
+def test_auxiliary_layer_ops_under_fake_mode():
+    """Max pooling and the fused mean losses return new tensors: their fakes must predict shape, dtype and device."""
+    with FakeTensorMode():
+        x = cuda(2, 9, 4, 7, 8, dtype=torch.bfloat16)
+        y = torch.ops.sr355.maxpool2x2_fwd(x)
+        assert y.shape == (2, 4, 4, 3, 8) and y.dtype == torch.bfloat16 and y.device.type == "cuda"
+        dx = torch.ops.sr355.maxpool2x2_bwd(x, y)
+        assert dx.shape == x.shape and dx.dtype == torch.bfloat16
+        a, b = cuda(3, 5, 7), cuda(3, 5, 7)
+        for other, want in ((b, True), (None, False)):
+            loss, grad = torch.ops.sr355.loss_fwd(a, other, 1.0, 1, want)
+            assert loss.shape == () and loss.dtype == torch.float32
+            assert grad.shape == (a.shape if want else (0,))
