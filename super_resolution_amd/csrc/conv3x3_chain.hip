@@ -191,8 +191,10 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
                               acc[0][nb][4 * q + 2] + bv[q].z, acc[0][nb][4 * q + 3] + bv[q].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[0][nb][4 * q + e] = 0.f;
+                // LeakyReLU as max(v, slope * v): the same value as the compare-and-select of the other epilogues for
+                // a slope in [0, 1] (the launcher checks it), one instruction per element and no condition register
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], v[j] * slope);
                 if constexpr (has_ra) {
                     const epi_bf16x4 rv = __builtin_bit_cast(epi_bf16x4, ra[i][q]);
 #pragma unroll
@@ -621,7 +623,8 @@ int chain_resident_workgroups(int *out) {
 
 bool chain_supported(const ConvArgs &a, int cin_units) {
     return a.ups == 0 && a.zins == 0 && !a.f16_in && a.stride != 2 && (cin_units % RSU) == 0 && cin_units >= 2 * RSU &&
-           (a.cout_pad == 32 || a.cout_pad == 64) && a.cout_real == a.cout_pad && !a.out_nchw && !a.out_u8 && a.out_act && !a.mask_act;
+           (a.cout_pad == 32 || a.cout_pad == 64) && a.cout_real == a.cout_pad && !a.out_nchw && !a.out_u8 && a.out_act && !a.mask_act &&
+           a.slope >= 0.f && a.slope <= 1.f;
 }
 
 int launch_conv3x3_chain(const ChainArgs &c0, int max_workgroups, hipStream_t stream) {
