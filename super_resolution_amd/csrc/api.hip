@@ -1123,6 +1123,18 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                     fprintf(stderr, "chain trace: %-60s p10 %9.1f median %9.1f p90 %9.1f us\n", names[k], v[nwg / 10],
                             v[nwg / 2], v[nwg * 9 / 10]);
                 }
+                if (const char *path = getenv("SR355_CHAIN_TRACE_CSV")) {
+                    if (FILE *f = fopen(path, "w")) {
+                        fprintf(f, "wg,xcc,se,cu,shader_mhz,total_us,poll_us,epilogue_us\n");
+                        for (int b = 0; b < nwg; ++b) {
+                            const unsigned long long *w = &t[(size_t)b * 12];
+                            const unsigned hw = (unsigned)w[11], xcc = (unsigned)(w[11] >> 32) & 15;
+                            fprintf(f, "%d,%u,%u,%u,%.1f,%.1f,%.1f,%.1f\n", b, xcc, (hw >> 13) & 7, (hw >> 8) & 15,
+                                    (double)w[10] / (w[7] * 0.01), w[7] * 0.01, w[0] * 0.01, w[3] * 0.01);
+                        }
+                        fclose(f);
+                    }
+                }
             }
         }
 #endif

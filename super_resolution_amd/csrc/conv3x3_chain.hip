@@ -89,9 +89,14 @@ typedef ChainGeo G;
 // lanes 12-15 and 28-31 of each half-wave stored (measured; plain 16-byte stores and 8-byte write-through stores of
 // the other kernels do not show it).  The store therefore goes out as inline asm with 16 wait states (a quarter-wave
 // of four dwords per cycle) inside the same statement, where nothing can be scheduled between.
+// The compiler's hazard recogniser does not look inside an asm statement: a scalar register written by a vector
+// instruction (v_readlane reloading a spilled SGPR, v_readfirstlane) must not be read by a memory instruction within
+// five wait states, and the store's descriptor and scalar offset are such registers.  The five wait states are part
+// of the statement (without them a build whose spill reload landed directly in front of the store wrote to stale
+// addresses whenever the wave issued back to back).
 typedef int chain_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void chain_store16(const epi_v4u &data, chain_v4i rsrc, int voffset, int soffset) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 15"
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 15"
                  :
                  : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
                  : "memory");
@@ -283,6 +288,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         const int q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         first = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
+    // The dispatcher fills every CU once and then a second time: blocks b and b + nwg/2 share a CU, and its
+    // instruction arbiter serves the older wave first, so the first half of the grid would run ahead and leave the
+    // second half to finish alone on half-empty CUs.  The blocks of the second half therefore run at wave priority 1
+    // and those of the first half alternate between 2 and 0, pass by pass: one of the two blocks of a CU always runs
+    // at full speed, the other fills its gaps, and both advance at about the same rate.  (Where the pairing does not
+    // hold the priorities are merely arbitrary.)
+    const bool prio_alternates = (int)blockIdx.x < (nwg >> 1);
+    if (!prio_alternates) __builtin_amdgcn_s_setprio(1);
     const int n_my = first < n_tiles ? (n_tiles - first + nwg - 1) / nwg : 0;
     const int n_ord = c.n_passes * n_my;          // this workgroup's tasks: pass-major, its tiles within a pass
     if (n_ord == 0) return;
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
 #ifdef SR355_TRACE
     unsigned long long tr_[12] = {};
     const unsigned long long tr_start_ = wall_clock64();
+    const unsigned long long tr_cycles_ = clock64();
 #endif
     f32x16 acc[1][NB];
 #pragma unroll
@@ -423,8 +437,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                              \
             WF[ky] = *reinterpret_cast<const bf16x8 *>(pw + ((ky * 3 + (KX)) * G::CO) * 16);          \
         _Pragma("unroll") for (int rho = 0; rho < NB + 2; ++rho)                                      \
-            XF[rho] = *reinterpret_cast<const bf16x8 *>(pin + (rho * TWP + (KX)) * 16);               \
+            if (SR355_EXP_KEEP(KX)) XF[rho] = *reinterpret_cast<const bf16x8 *>(pin + (rho * TWP + (KX)) * 16); \
+            else XF[rho] = exp_prev_[rho];                                                            \
+        _Pragma("unroll") for (int rho = 0; rho < NB + 2; ++rho) exp_prev_[rho] = XF[rho];            \
     }
+#ifdef SR355_EXP_READS
+#define SR355_EXP_KEEP(KX) ((KX) == 0)
+#else
+#define SR355_EXP_KEEP(KX) true
+#endif
 #define SR355_MMA_FRAGS(WF, XF)                                                                       \
     {                                                                                                 \
         _Pragma("unroll") for (int rho = 0; rho < NB + 2; ++rho)                                      \
@@ -465,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     int ct_i = -1, ct_tx = 0, ct_ty = 0, ct_n = 0;
     for (int ord = 0; ord < n_ord; ++ord) {
         const int p = ord / n_my;
+        if (prio_alternates) {
+            if (p & 1) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(2);
+        }
         {
             const int i = ord - p * n_my;
             if (i != ct_i) {
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             const unsigned char *buf = smem + slot * G::STAGE_BYTES;
             const unsigned char *pin = buf + lane_in;
             const unsigned char *pw = buf + lane_w;
-            bf16x8 wfA[3], xfA[NB + 2], wfB[3], xfB[NB + 2];
+            bf16x8 wfA[3], xfA[NB + 2], wfB[3], xfB[NB + 2], exp_prev_[NB + 2];
             SR355_LOAD_FRAGS(wfA, xfA, 0);
             __builtin_amdgcn_sched_barrier(0);
             // column 0: its MFMAs, the reads of column 1 and this stage's DMA issue, one of each at a time
@@ -577,6 +602,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
 #ifdef SR355_TRACE
     if (c.trace && tid == 0) {
         tr_[7] = wall_clock64() - tr_start_;
+        tr_[10] = clock64() - tr_cycles_;      // shader-clock cycles over the same interval as tr_[7]
+        tr_[11] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |   // XCC_ID
+                  (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                        // HW_ID
         for (int k = 0; k < 12; ++k) c.trace[blockIdx.x * 12 + k] = tr_[k];
     }
 #endif
