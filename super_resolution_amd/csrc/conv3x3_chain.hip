@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     int ct_i = -1, ct_tx = 0, ct_ty = 0, ct_n = 0;
     for (int ord = 0; ord < n_ord; ++ord) {
         const int p = ord / n_my;
-        if (prio_alternates) {
-            if (p & 1) __builtin_amdgcn_s_setprio(0);
-            else __builtin_amdgcn_s_setprio(2);
+        if (prio_alternates) {   // (measured: per pass beats per stage and per two passes; this parity balances the halves)
+            if (p & 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
         }
         {
             const int i = ord - p * n_my;
