@@ -1588,8 +1588,13 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // stream beside the chain (a data gradient at training sizes fills a fraction of the chip).  Every wgrad
     // waits for what the main stream has issued so far; the main stream waits for a dense block's wgrads
     // before it overwrites the gradient stack they read (one block later), and for all of them at the end.
-    static const int side_knob = [] { const char *e = getenv("SR355_WGRAD_STREAM"); return e ? atoi(e) : 1; }();
-    SideStream *ss = side_knob ? side_stream() : nullptr;
+    // Not with the one-launch dense block: its workgroup takes a CU's whole LDS, so a weight-gradient workgroup
+    // cannot share a CU with it, the two kernels only displace each other, and the event traffic doubles the host
+    // time of the call (measured at 16 x 32 x 32: 7.2 ms per pixel iteration with the side stream, 6.8 without;
+    // with one launch per conv, 64 x 64 and up, the side stream gains 2-10 %).  SR355_WGRAD_STREAM=0 / 1 forces it.
+    const bool fused = use_dense_fused(cfg, N, H, W);
+    static const int side_knob = [] { const char *e = getenv("SR355_WGRAD_STREAM"); return e ? atoi(e) : -1; }();
+    SideStream *ss = (side_knob < 0 ? !fused : side_knob != 0) ? side_stream() : nullptr;
     std::unique_lock<std::mutex> side_lock;
     if (ss) side_lock = std::unique_lock<std::mutex>(ss->in_use);
     hipStream_t wstream = ss ? ss->stream[0] : stream;
@@ -1643,7 +1648,6 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // writes the next stack's units [0, nf) only after the weight gradients that read that stack are done).  One
     // launch per block: three, because the single launch also fills its own stack's growth units, which must not
     // be the stack the previous block's weight gradients are still reading.
-    const bool fused = use_dense_fused(cfg, N, H, W);
     const int n_gb = fused ? 3 : 2;
     unsigned char *GB[3] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2};
     if (phase_begin == 0) {

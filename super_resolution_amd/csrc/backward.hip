@@ -47,10 +47,12 @@ __device__ __forceinline__ void pack_weight_t_body(const float *__restrict__ w, 
     const int units = (Co + CPU - 1) / CPU;
     const int total = units * 9 * cout_pad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int o = i % cout_pad;
-        const int t = i / cout_pad;
-        const int tap = t % 9;
-        const int u = t / 9;
+        // consecutive threads take consecutive (output, tap) pairs of one unit: their reads of w are consecutive
+        // floats (the 16-byte stores are scattered instead; there are eight reads to one store)
+        const int tap = 8 - i % 9;
+        const int t = i / 9;
+        const int o = t % cout_pad;
+        const int u = t / cout_pad;
         T v[CPU];
 #pragma unroll
         for (int e = 0; e < CPU; ++e) {
@@ -397,69 +399,91 @@ __global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { 
 
 // dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32], and, when db is given,
 // db[co] (=|+=) scale * sum_g bias_slab[g][co]; a fixed summation order, so results are reproducible.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int cout, int cin, int CO,
-                                    int G, float scale, int accumulate, const float *__restrict__ bias_slabs,
-                                    float *__restrict__ db) {
-    const int n_w = 9 * cout * cin;
-    const int total = n_w + (db ? cout : 0);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        if (i >= n_w) {
-            const int co = i - n_w;
-            float sum = 0.f;
-            for (int gidx = 0; gidx < G; ++gidx) sum += bias_slabs[(size_t)gidx * CO + co];
-            db[co] = accumulate ? db[co] + scale * sum : scale * sum;
-            continue;
-        }
-        const int ci = i % cin;
-        const int t = i / cin;
-        const int co = t % cout;
-        const int tap = t / cout;
-        const float *s = slabs + ((size_t)(ci >> 5) * G * 9 + tap) * CO * 32 + co * 32 + (ci & 31);
-        float sum = 0.f;
-        for (int gidx = 0; gidx < G; ++gidx) sum += s[(size_t)gidx * 9 * CO * 32];
-        float *d = dw + ((size_t)co * cin + ci) * 9 + tap;
-        *d = accumulate ? *d + scale * sum : scale * sum;
-    }
-}
-
-// The same reduction for up to five convs in one launch (blockIdx.y = conv).
+// One workgroup of 256 threads = 64 items x 4 waves; an item is four consecutive input channels of one (tap, output)
+// pair (one float4 of a slab row).  Wave k sums the slabs g = k, k + 4, ...; the four partial sums are added in wave
+// order through the LDS.  Bias items (one output channel each) follow the weight items.
 struct WgradReduceJob {
     const float *slabs, *bias_slabs;
     float *dw, *db;
     int cout, cin, CO, G;
     float scale;
 };
+__device__ __forceinline__ void wgrad_reduce_body(const WgradReduceJob &j, int accumulate) {
+    __shared__ float4 part[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cin4 = (j.cin + 3) >> 2;
+    const int n_w = 9 * j.cout * cin4;
+    const int total = n_w + (j.db ? j.cout : 0);
+    for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {   // (uniform per workgroup: barriers inside)
+        const int i = base + lane;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        int ci = 0, co = 0, tap = 0;
+        const bool is_w = i < n_w, is_b = !is_w && i < total;
+        if (is_w) {
+            ci = (i % cin4) * 4;
+            const int tt = i / cin4;
+            co = tt % j.cout;
+            tap = tt / j.cout;
+            const float *s = j.slabs + ((size_t)(ci >> 5) * j.G * 9 + tap) * j.CO * 32 + co * 32 + (ci & 31);
+            const size_t stride = (size_t)9 * j.CO * 32;
+            for (int g = wave; g < j.G; g += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(s + g * stride);
+                sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+            }
+        } else if (is_b) {
+            co = i - n_w;
+            for (int g = wave; g < j.G; g += 4) sum.x += j.bias_slabs[(size_t)g * j.CO + co];
+        }
+        if (wave) part[wave - 1][lane] = sum;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 v = part[k][lane];
+                sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+            }
+            if (is_w) {
+                const float r[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ci + e >= j.cin) break;
+                    float *d = j.dw + ((size_t)co * j.cin + ci + e) * 9 + tap;
+                    *d = accumulate ? *d + j.scale * r[e] : j.scale * r[e];
+                }
+            } else if (is_b) {
+                j.db[co] = accumulate ? j.db[co] + j.scale * sum.x : j.scale * sum.x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32], and, when db is given,
+// db[co] (=|+=) scale * sum_g bias_slab[g][co]; a fixed summation order, so results are reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw,
+                                                           int cout, int cin, int CO, int G, float scale,
+                                                           int accumulate, const float *__restrict__ bias_slabs,
+                                                           float *__restrict__ db) {
+    const WgradReduceJob j = {slabs, bias_slabs, dw, db, cout, cin, CO, G, scale};
+    wgrad_reduce_body(j, accumulate);
+}
+
+// The same reduction for up to five convs in one launch (blockIdx.y = conv).
 struct WgradReduceTable {
     WgradReduceJob j[5];
 };
-__global__ void wgrad_reduce_batch_kernel(const WgradReduceTable t, int accumulate) {
-    const WgradReduceJob &j = t.j[blockIdx.y];
-    const int n_w = 9 * j.cout * j.cin;
-    const int total = n_w + (j.db ? j.cout : 0);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        if (i >= n_w) {
-            const int co = i - n_w;
-            float sum = 0.f;
-            for (int gidx = 0; gidx < j.G; ++gidx) sum += j.bias_slabs[(size_t)gidx * j.CO + co];
-            j.db[co] = accumulate ? j.db[co] + j.scale * sum : j.scale * sum;
-            continue;
-        }
-        const int ci = i % j.cin;
-        const int tt = i / j.cin;
-        const int co = tt % j.cout;
-        const int tap = tt / j.cout;
-        const float *s = j.slabs + ((size_t)(ci >> 5) * j.G * 9 + tap) * j.CO * 32 + co * 32 + (ci & 31);
-        float sum = 0.f;
-        for (int gidx = 0; gidx < j.G; ++gidx) sum += s[(size_t)gidx * 9 * j.CO * 32];
-        float *d = j.dw + ((size_t)co * j.cin + ci) * 9 + tap;
-        *d = accumulate ? *d + j.scale * sum : j.scale * sum;
-    }
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceTable t, int accumulate) {
+    wgrad_reduce_body(t.j[blockIdx.y], accumulate);
 }
 
 // ------------------------------------------------------------------------------------------
 static unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+static unsigned reduce_grid_for(size_t items) {   // 64 items per workgroup of the weight-gradient reductions
+    size_t b = (items + 63) / 64;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 int launch_pack_weight_t(const float *w, int Co, int Ci, int ci_lo, int n_out, int dtype, float scale, void *wp,
@@ -601,8 +625,8 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
     a.n_batch = 4 + n5;
     hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4 + n5), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
     if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
-    const size_t biggest = (size_t)9 * nf * (nf + 4 * gc) + nf;
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(grid_for(biggest), 5), dim3(256), 0, stream, rt, 0);
+    const size_t biggest = (size_t)9 * nf * ((nf + 4 * gc + 3) / 4) + nf;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(reduce_grid_for(biggest), 5), dim3(256), 0, stream, rt, 0);
     return check_hip(hipGetLastError(), "wgrad reduce batch launch");
 }
 
@@ -647,8 +671,8 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
     else
         hipLaunchKernelGGL(wgrad3x3_kernel_mb1, grid, dim3(192), WGeo<1>::LDS_BYTES, stream, a);
     if (check_hip(hipGetLastError(), "wgrad3x3 launch")) return SR355_ERR_HIP;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((size_t)9 * cout * cin + cout)), dim3(256), 0, stream, slabs,
-                       dw, cout, cin, co_pad, G, scale, accumulate, a.bias_slabs, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid_for((size_t)9 * cout * ((cin + 3) / 4) + cout)), dim3(256), 0,
+                       stream, slabs, dw, cout, cin, co_pad, G, scale, accumulate, a.bias_slabs, db);
     if (check_hip(hipGetLastError(), "wgrad reduce launch")) return SR355_ERR_HIP;
     return SR355_OK;
 }
