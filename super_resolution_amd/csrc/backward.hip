@@ -505,9 +505,9 @@ int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream
         const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
         for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
         if (dtype == SR355_DTYPE_BF16)
-            hipLaunchKernelGGL(pack_weight_t_batch_kernel<__bf16>, dim3(8, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<__bf16>, dim3(32, m), dim3(256), 0, stream, t);
         else
-            hipLaunchKernelGGL(pack_weight_t_batch_kernel<float>, dim3(8, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<float>, dim3(32, m), dim3(256), 0, stream, t);
         if (check_hip(hipGetLastError(), "pack_weight_t batch launch")) return SR355_ERR_HIP;
     }
     return SR355_OK;

@@ -86,10 +86,13 @@ __device__ __forceinline__ void pack_weight_body(const float *__restrict__ w, co
     constexpr int CPU = 16 / sizeof(T);
     const int total = U * (split ? 2 : 1) * 9 * cout_pad;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int co = i % cout_pad;
-        const int t = i / cout_pad;
-        const int tap = t % 9;
-        const int uu = t / 9;
+        // consecutive threads take consecutive (unit, tap) pairs of one output channel: together their eight reads
+        // cover whole cache lines of w (the 16-byte stores are scattered instead)
+        const int UU = U * (split ? 2 : 1);
+        const int tap = i % 9;
+        const int t = i / 9;
+        const int uu = t % UU;
+        const int co = t / UU;
         const int image = uu >= U ? 1 : 0;
         const int u = uu - image * U;
         T v[CPU];
@@ -106,7 +109,7 @@ __device__ __forceinline__ void pack_weight_body(const float *__restrict__ w, co
         }
         uint4 pk;
         __builtin_memcpy(&pk, v, 16);
-        reinterpret_cast<uint4 *>(wp)[i] = pk;
+        reinterpret_cast<uint4 *>(wp)[((size_t)uu * 9 + tap) * cout_pad + co] = pk;
         if (i < cout_pad && bp) bp[i] = (i < cout && bias) ? bias[i] : 0.f;
     }
 }
@@ -244,9 +247,9 @@ int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t 
         const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
         for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
         if (dtype == SR355_DTYPE_BF16)
-            hipLaunchKernelGGL(pack_weight_batch_kernel<__bf16>, dim3(16, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_batch_kernel<__bf16>, dim3(48, m), dim3(256), 0, stream, t);
         else
-            hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(16, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(48, m), dim3(256), 0, stream, t);
         if (check_hip(hipGetLastError(), "pack_weight batch launch")) return SR355_ERR_HIP;
     }
     return SR355_OK;
