@@ -84,19 +84,18 @@ typedef ChainGeo G;
 //     counter: a load issued behind a store cannot be waited for without waiting for that store, and a write-through
 //     store takes microseconds.
 // A chain pass has no sign mask and no NCHW / uint8 output (chain_supported).
-// A 16-byte write-through store reads its data registers for longer after it issues than the compiler allows for: with
-// the store builtin, arithmetic of the next quad that reused those registers three instructions later changed what
-// lanes 12-15 and 28-31 of each half-wave stored (measured; plain 16-byte stores and 8-byte write-through stores of
-// the other kernels do not show it).  The store therefore goes out as inline asm with 16 wait states (a quarter-wave
-// of four dwords per cycle) inside the same statement, where nothing can be scheduled between.
-// The compiler's hazard recogniser does not look inside an asm statement: a scalar register written by a vector
-// instruction (v_readlane reloading a spilled SGPR, v_readfirstlane) must not be read by a memory instruction within
-// five wait states, and the store's descriptor and scalar offset are such registers.  The five wait states are part
-// of the statement (without them a build whose spill reload landed directly in front of the store wrote to stale
-// addresses whenever the wave issued back to back).
+// The 16-byte write-through store goes out as inline asm, and the compiler's hazard recogniser does not look inside an
+// asm statement.  Two of the architecture's manual wait-state rules apply to it and are part of the statement:
+//   * a scalar register written by a vector instruction (v_readlane reloading a spilled SGPR, v_readfirstlane) must not
+//     be read by a memory instruction within five wait states, and the store's descriptor and scalar offset are such
+//     registers (a build whose spill reload landed directly in front of the store wrote to stale addresses whenever
+//     the wave issued back to back);
+//   * the data registers of a store of more than 64 bits must not be overwritten by a vector instruction within two
+//     wait states of its issue: the next quad's arithmetic reuses them, and without wait states here the kernel stores
+//     wrong values (tests/test_gpu_chain.py fails).  Four are inserted.
 typedef int chain_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void chain_store16(const epi_v4u &data, chain_v4i rsrc, int voffset, int soffset) {
-    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 15"
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 3"
                  :
                  : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
                  : "memory");
