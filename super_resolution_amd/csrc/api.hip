@@ -1048,6 +1048,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                     set_error("generator forward: chain pass with %d stages cannot be ordered", S);
                     return SR355_ERR_UNSUPPORTED;
                 }
+                chain_fill_cursor(ps);
                 passes.push_back(ps);
             }
             prev_blocks = cc.a.cout_pad / 32;

@@ -65,7 +65,8 @@ struct ChainGeo {
     static constexpr int W_OFF = NIN_I * 1024;
     static constexpr int STAGE_BYTES = JTOT * 1024;
     static constexpr int BIAS_OFF = 2 * STAGE_BYTES;           // two bias images: the pass in its epilogue, the next one
-    static constexpr int DUMMY_OFF = BIAS_OFF + 512;           // landing area of the padding loads
+    static constexpr int CUR_OFF = BIAS_OFF + 512;             // two cursor records (64 bytes used of 256 each)
+    static constexpr int DUMMY_OFF = CUR_OFF + 512;            // landing area of the padding loads
     static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
     static constexpr int N_READS = 3 + NB + 2;                 // LDS reads of one tap column
     static constexpr int N_MFMA = 3 * NB;                      // MFMAs of one tap column
@@ -309,23 +310,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     int voff[G::KMAX];
     int in_lo = 0, in_hi = 0, w_lo = 0, w_hi = 0, w_len = 0, w_stage_stride = 0;
     const int in_len = __builtin_amdgcn_readfirstlane(img_bytes);
-    int it_ord = 0, it_stage = 0, it_S = 0, it_dep = 0, it_need = 0, it_dep2 = 0, it_need2 = 0, it_p = 0;
+    int it_ord = 0, it_stage = 0, it_S = 0, it_dep = 0, it_need = 0, it_dep2 = 0, it_need2 = 0, it_p = -1;
     int it_tx = 0, it_ty = 0, it_n = 0, it_i = -1;
 
+    int cur_in_lo = 0, cur_in_hi = 0, cur_b_lo = 0, cur_b_hi = 0, cur_cout_pad = 32;
+    // the 64-byte cursor record of pass P into LDS slot P & 1 (wave 0; lanes 16.. read beyond the range: zeros)
+#define SR355_CURSOR_DMA(P)                                                                           \
+    {                                                                                                 \
+        const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(                      \
+            const_cast<ChainPass *>(c.passes) + (P), 0, (int)sizeof(ChainCursor), 0x00020000);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rsrc, (lds_void *)(smem + G::CUR_OFF + ((P)&1) * 256), 4, lane * 4, \
+                                                 0, 0, 0);                                            \
+    }
     // Set the cursor up for task ORD: descriptor of its pass, tile coordinates, per-lane source offsets, bias image.
 #define SR355_TASK_SETUP(ORD)                                                                         \
     {                                                                                                 \
         const int p_ = (ORD) / n_my;                                                                  \
         const int i_ = (ORD)-p_ * n_my;                                                               \
-        cpass_t *d_ = passes + p_;                                                                    \
-        it_S = d_->a.n_stages, it_dep = d_->dep_stage, it_need = d_->need;                            \
-        it_dep2 = d_->dep2_stage, it_need2 = d_->need2, it_p = p_;                                    \
-        const int cout_pad_ = d_->a.cout_pad;                                                         \
-        w_stage_stride = RSU * 9 * cout_pad_ * 16;                                                    \
-        const unsigned long long wb_ = (unsigned long long)(d_->a.w);                                 \
-        w_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)wb_);                                    \
-        w_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(wb_ >> 32));                            \
-        w_len = __builtin_amdgcn_readfirstlane(w_stage_stride * it_S);                                \
+        if (p_ != it_p) {                                                                             \
+            /* the pass's cursor record, brought into the LDS when the cursor entered the pass before (landed: a   */ \
+            /* stage boundary lies in between); then the request for the next pass's record                        */ \
+            chain_v4i r0_, r1_, r2_;                                                                  \
+            const unsigned ra_ = (unsigned)(size_t)(smem + G::CUR_OFF + (p_ & 1) * 256);              \
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\t" \
+                         "s_waitcnt lgkmcnt(0)"                                                       \
+                         : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_)                                         \
+                         : "v"(ra_)                                                                   \
+                         : "memory");                                                                 \
+            w_lo = __builtin_amdgcn_readfirstlane(r0_[0]), w_hi = __builtin_amdgcn_readfirstlane(r0_[1]); \
+            cur_in_lo = __builtin_amdgcn_readfirstlane(r0_[2]), cur_in_hi = __builtin_amdgcn_readfirstlane(r0_[3]); \
+            cur_b_lo = __builtin_amdgcn_readfirstlane(r1_[0]), cur_b_hi = __builtin_amdgcn_readfirstlane(r1_[1]); \
+            it_S = __builtin_amdgcn_readfirstlane(r1_[2]);                                            \
+            cur_cout_pad = __builtin_amdgcn_readfirstlane(r1_[3]);                                    \
+            it_need = __builtin_amdgcn_readfirstlane(r2_[0]), it_dep = __builtin_amdgcn_readfirstlane(r2_[1]); \
+            it_need2 = __builtin_amdgcn_readfirstlane(r2_[2]), it_dep2 = __builtin_amdgcn_readfirstlane(r2_[3]); \
+            it_p = p_;                                                                                \
+            w_stage_stride = RSU * 9 * cur_cout_pad * 16;                                             \
+            w_len = w_stage_stride * it_S;                                                            \
+            if (wave == 0 && p_ + 1 < c.n_passes) SR355_CURSOR_DMA(p_ + 1);                           \
+        }                                                                                             \
+        const int cout_pad_ = cur_cout_pad;                                                           \
         const bool new_tile_ = i_ != it_i;                                                            \
         if (new_tile_) {                                                                              \
             const int t_ = first + i_ * nwg;                                                          \
@@ -335,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             it_n = tr_ / c.tiles_y;                                                                   \
             it_i = i_;                                                                                \
         }                                                                                             \
-        const unsigned long long ib_ = (unsigned long long)(d_->a.in) + (size_t)it_n * img_bytes;     \
+        const unsigned long long ib_ = (((unsigned long long)(unsigned)cur_in_hi << 32) | (unsigned)cur_in_lo) + \
+                                       (size_t)it_n * img_bytes;                                      \
         in_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ib_);                                   \
         in_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib_ >> 32));                           \
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                         \
@@ -363,8 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             }                                                                                         \
         }                                                                                             \
         if (wave == 0) {                                                                              \
-            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(                  \
-                const_cast<float *>(d_->a.bias), 0, G::CO * 4, 0x00020000);                           \
+            const __amdgpu_buffer_rsrc_t b_rsrc = SR355_RSRC(cur_b_lo, cur_b_hi, G::CO * 4);          \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void *)(smem + G::BIAS_OFF + ((ORD)&1) * 256), 4,  \
                                                      lane * 4, 0, 0, 0);                              \
         }                                                                                             \
@@ -470,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
 #define SR355_CURSOR_HELD(CUR_P) (it_ord < n_ord && it_stage == 0 && it_dep == 0 && it_need > (CUR_P))
 
     // ---- prologue: first task, first stage ----
+    if (wave == 0) SR355_CURSOR_DMA(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     SR355_TASK_SETUP(0);
     if (SR355_CURSOR_HELD(-1) && it_need > 0) {   // (a chain whose first pass reads another launch's output has need = 0)
         SR355_AWAIT_NEIGHBOURS(it_need);
@@ -608,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     }
 #endif
 #undef SR355_RSRC
+#undef SR355_CURSOR_DMA
 #undef SR355_TASK_SETUP
 #undef SR355_ISSUE_DMA
 #undef SR355_AWAIT_NEIGHBOURS

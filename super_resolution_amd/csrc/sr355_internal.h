@@ -69,7 +69,17 @@ struct DenseArgs {
 };
 
 // One pass of the chain kernel (conv3x3_chain.hip): a conv restricted to one block of 32 output channels.
+// What the DMA cursor needs of a pass, 64 bytes in front of its descriptor: the kernel brings the next pass's record
+// into the LDS one pass ahead (one dword per lane of a 16-lane load) instead of waiting on scalar loads when it gets there.
+struct ChainCursor {
+    unsigned long long w, in, bias;   // = a.w, a.in, a.bias
+    int n_stages, cout_pad;           // = a.n_stages, a.cout_pad
+    int need, dep_stage, need2, dep2_stage;
+    int pad[4];
+};
+static_assert(sizeof(ChainCursor) == 64, "one dword per lane of a quarter-wave");
 struct ChainPass {
+    ChainCursor cur;  // filled by launch_conv3x3_chain's caller through chain_fill_cursor
     ConvArgs a;       // w and bias already point at the block; n_stages set; N/H/W/in_units as in ChainArgs
     int cb_co;        // first output channel of the block
     int need;         // passes that must be complete on the neighbouring tiles before stage dep_stage is requested
@@ -78,6 +88,13 @@ struct ChainPass {
     int dep2_stage;   // needed from stage 0, the second one's from dep2_stage >= 2); need2 = 0: none
     int pad[3];
 };
+inline void chain_fill_cursor(ChainPass &ps) {
+    ps.cur.w = (unsigned long long)ps.a.w, ps.cur.in = (unsigned long long)ps.a.in;
+    ps.cur.bias = (unsigned long long)ps.a.bias;
+    ps.cur.n_stages = ps.a.n_stages, ps.cur.cout_pad = ps.a.cout_pad;
+    ps.cur.need = ps.need, ps.cur.dep_stage = ps.dep_stage, ps.cur.need2 = ps.need2, ps.cur.dep2_stage = ps.dep2_stage;
+    ps.cur.pad[0] = ps.cur.pad[1] = ps.cur.pad[2] = ps.cur.pad[3] = 0;
+}
 struct ChainArgs {
     const ChainPass *passes;   // device memory, written before the launch
     int n_passes;
