@@ -484,7 +484,7 @@ int sr355_pool2x2_sum(const void *in, size_t in_bytes, int N, int H, int W, int 
 }
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
-    if (cout < 1 || cout > 64 || cin < 1 || N < 1 || H < 1 || W < 1) return 0;
+    if (cout < 1 || cin < 1 || N < 1 || H < 1 || W < 1 || (cout > 64 && (cout & 31)) || cout > 4096) return 0;
     return wgrad_workspace_bytes(cout, cin, N, H, W);
 }
 
@@ -494,7 +494,8 @@ static int wgrad_checks(const char *who, const sr355_wgrad_args *p, const void *
         set_error("%s: args is null", who);
         return SR355_ERR_INVALID;
     }
-    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || p->cout > 64 || p->cin < 1 ||
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || (p->cout > 64 && (p->cout & 31)) || p->cout > 4096 ||
+        p->cin < 1 ||
         (p->upsample != 0 && p->upsample != 1) || (p->upsample && ((p->H | p->W) & 1))) {
         set_error("%s: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d", who, p->N, p->H, p->W, p->cout,
                   p->cin, p->upsample);

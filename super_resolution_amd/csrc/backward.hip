@@ -147,6 +147,7 @@ __global__ void pool2x2_kernel(const T *__restrict__ in, int N, int H, int W, in
 // Weight gradient.  Workgroup = 3 waves; wave ky owns the three taps of kernel row ky.  Work item =
 // (4 x 32 pixel tile, chunk of 32 input channels); a workgroup sums its items in registers and
 // writes one slab [9][CO][32] at the end.
+constexpr int WGRAD_MAX_JOBS = 16;   // convs (or 32-output slices of one conv) a batched launch takes
 struct WgradArgs {
     const unsigned char *in;   // blocked bf16 activations (conv input)
     const unsigned char *dy;   // blocked bf16 gradient of the conv output
@@ -161,9 +162,9 @@ struct WgradArgs {
     // batched launch (blockIdx.z = conv of a dense block sharing `in` and `dy`): per-conv channel chunks,
     // workgroups per chunk, position of its gradient in dy and of its slabs; n_batch = 0: single conv
     int n_batch;
-    int z_chunks[6], z_groups[6], z_dy_unit_off[6];
-    int z_co_off[6], z_co_stride[6];          // a job's 32 outputs sit at rows [co_off, co_off + 32) of slabs co_stride wide
-    long long z_slab_off[6], z_bias_off[6];   // in floats from `slabs`; bias < 0: none
+    int z_chunks[WGRAD_MAX_JOBS], z_groups[WGRAD_MAX_JOBS], z_dy_unit_off[WGRAD_MAX_JOBS];
+    int z_co_off[WGRAD_MAX_JOBS], z_co_stride[WGRAD_MAX_JOBS];   // a job's 32 outputs sit at rows [co_off, co_off + 32) of slabs co_stride wide
+    long long z_slab_off[WGRAD_MAX_JOBS], z_bias_off[WGRAD_MAX_JOBS];   // in floats from `slabs`; bias < 0: none
 };
 
 namespace {
@@ -468,9 +469,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     wgrad_reduce_body(j, accumulate);
 }
 
-// The same reduction for up to five convs in one launch (blockIdx.y = conv).
+// The same reduction for up to WGRAD_MAX_JOBS convs or slices in one launch (blockIdx.y = job).
 struct WgradReduceTable {
-    WgradReduceJob j[5];
+    WgradReduceJob j[WGRAD_MAX_JOBS];
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceTable t, int accumulate) {
     wgrad_reduce_body(t.j[blockIdx.y], accumulate);
@@ -540,7 +541,14 @@ void wgrad_geometry(int cin, int N, int H, int W, int *chunks, int *G) {
     *G = (int)g;
 }
 
+static size_t wgrad_slice_floats(int cin, int N, int H, int W) {   // one 32-output slice of a sliced launch, 256-byte units
+    int chunks, G;
+    wgrad_geometry(cin, N, H, W, &chunks, &G);
+    return ((((size_t)chunks * G * 9 * 32 + G) * 32 * sizeof(float) + 255) & ~(size_t)255) / sizeof(float);
+}
+
 size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
+    if (cout > 64) return (size_t)((cout + 31) / 32) * wgrad_slice_floats(cin, N, H, W) * sizeof(float);
     int chunks, G;
     wgrad_geometry(cin, N, H, W, &chunks, &G);
     // weight slabs, then one row of per-workgroup bias sums
@@ -630,12 +638,67 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
     return check_hip(hipGetLastError(), "wgrad reduce batch launch");
 }
 
+// A conv with more than 64 output channels (a multiple of 32): its 32-output slices are the jobs of batched launches
+// (blockIdx.z = slice, all reading the same input), WGRAD_MAX_JOBS slices per launch, each followed by one batched
+// reduction.  One launch per 64 outputs would leave most of the chip idle at the small images such layers have.
+static int launch_wgrad3x3_sliced(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off,
+                                  int N, int H, int W, int cout, int cin, float scale, int accumulate, float *dw,
+                                  float *db, float *slabs, hipStream_t stream, int dy_stride2) {
+    if (cout & 31) {
+        set_error("wgrad3x3: cout=%d not supported (more than 64 output channels must be a multiple of 32)", cout);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    int rc;
+    if ((rc = wgrad_set_attr(0))) return rc;
+    int chunks, G;
+    wgrad_geometry(cin, N, H, W, &chunks, &G);
+    const size_t slice_floats = wgrad_slice_floats(cin, N, H, W);
+    const int n_slices = cout / 32;
+    for (int s0 = 0; s0 < n_slices; s0 += WGRAD_MAX_JOBS) {
+        const int m = n_slices - s0 < WGRAD_MAX_JOBS ? n_slices - s0 : WGRAD_MAX_JOBS;
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = (const unsigned char *)in;
+        a.dy = (const unsigned char *)dy;
+        a.slabs = slabs;
+        a.N = N, a.H = H, a.W = W;
+        a.in_units = in_units, a.ups = ups;
+        a.dy_units = dy_units;
+        a.dy_s2 = dy_stride2 ? 1 : 0;
+        a.tiles_x = (W + 31) / 32;
+        a.tiles_y = (H + WTH - 1) / WTH;
+        a.n_batch = m;
+        WgradReduceTable rt;
+        memset(&rt, 0, sizeof(rt));
+        for (int k = 0; k < m; ++k) {
+            const int sl = s0 + k;
+            const size_t off = (size_t)sl * slice_floats;
+            const size_t bias_off = off + (size_t)chunks * G * 9 * 32 * 32;
+            a.z_chunks[k] = chunks, a.z_groups[k] = G, a.z_dy_unit_off[k] = dy_unit_off + sl * 4;
+            a.z_co_off[k] = 0, a.z_co_stride[k] = 32;
+            a.z_slab_off[k] = (long long)off;
+            a.z_bias_off[k] = db ? (long long)bias_off : -1;
+            rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw + (size_t)sl * 32 * cin * 9, db ? db + sl * 32 : nullptr,
+                                     32, cin, 32, G, scale};
+        }
+        hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(G, chunks, m), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
+        if (check_hip(hipGetLastError(), "wgrad3x3 sliced launch")) return SR355_ERR_HIP;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(reduce_grid_for((size_t)9 * 32 * ((cin + 3) / 4) + 32), m),
+                           dim3(256), 0, stream, rt, accumulate);
+        if (check_hip(hipGetLastError(), "wgrad sliced reduce launch")) return SR355_ERR_HIP;
+    }
+    return SR355_OK;
+}
+
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream, int dy_stride2) {
+    if (cout > 64)
+        return launch_wgrad3x3_sliced(in, in_units, ups, dy, dy_units, dy_unit_off, N, H, W, cout, cin, scale,
+                                      accumulate, dw, db, slabs, stream, dy_stride2);
     const int co_pad = cout_pad_for(cout);
     if (co_pad != 32 && co_pad != 64) {
-        set_error("wgrad3x3: cout=%d not supported (needs <= 64 output channels)", cout);
+        set_error("wgrad3x3: cout=%d not supported", cout);
         return SR355_ERR_UNSUPPORTED;
     }
     int chunks, G;

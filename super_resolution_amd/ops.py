@@ -335,10 +335,9 @@ def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
 
 def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor,
                       stride: int = 1) -> None:
-    """Weight / bias gradient of a conv with any number of output channels: ``sr355_conv3x3_wgrad`` takes at most 64
-    of them a call, so this walks ``dy`` in 64-channel slices — one argument block, one workspace and one device
-    context for all of them (a 512-channel layer is eight calls; built per call they cost more host time than
-    the kernels take)."""
+    """Weight / bias gradient of a conv with any number of output channels.  Up to 64, or any multiple of 32, is one
+    ``sr355_conv3x3_wgrad`` call (the library runs the 32-channel slices of a wide layer as the jobs of one batched
+    launch); other widths are walked in 64-channel slices with one argument block, workspace and device context."""
     _need_cuda(in_buf, dy, dw, db)
     if in_buf.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
         raise RuntimeError("conv3x3_wgrad runs on bf16 activations")
@@ -352,7 +351,8 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
     a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
     a.dy_dev, a.dy_bytes, a.dy_units = dy.data_ptr(), _nbytes(dy), int(dy.shape[2])
     a.scale, a.accumulate = 1.0, 0
-    need = L.sr355_wgrad_workspace_bytes(min(cout, 64), cin, N, H, W)
+    step = cout if (cout <= 64 or cout % 32 == 0) else 64
+    need = L.sr355_wgrad_workspace_bytes(step, cin, N, H, W)
     if need == 0:
         raise RuntimeError("conv3x3_wgrad: unsupported shape")
     ws = torch.empty(need, dtype=torch.uint8, device=dy.device)      # calls run in stream order: one workspace serves all
@@ -360,8 +360,8 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
     dw_ptr, db_ptr, row = dw.data_ptr(), db.data_ptr(), int(cin) * 9 * 4
     with _on(dy.device):
         stream = _stream()
-        for c0 in range(0, cout, 64):
-            cb = min(64, cout - c0)
+        for c0 in range(0, cout, step):
+            cb = min(step, cout - c0)
             a.dy_unit_off, a.cout = c0 // 8, cb
             a.dw_dev, a.dw_bytes, a.db_dev = dw_ptr + c0 * row, cb * row, db_ptr + c0 * 4
             check(L.sr355_conv3x3_wgrad(C.byref(a), stream), "sr355_conv3x3_wgrad")

@@ -122,6 +122,9 @@ WGRAD_CASES = [
     (1, 64, 64, 14, 38, 1),      # input stored at half resolution (nearest x2 fused in the forward)
     (1, 3, 64, 6, 40, 0),        # conv_first: 3 input channels in a padded unit
     (1, 64, 3, 9, 35, 0),        # conv_last: 3 output channels
+    (2, 40, 96, 7, 33, 0),       # more than 64 outputs: 32-channel slices as the jobs of one launch
+    (1, 64, 160, 12, 16, 0),
+    (1, 16, 544, 6, 20, 0),      # 17 slices: two launches
 ]
 
 
