@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 11
+#define SR355_ABI_VERSION 12
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -210,6 +210,14 @@ typedef struct sr355_wgrad_args {
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
 int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
+
+/* The same gradient on the exact-fp32 path (precision="fp32" modules under loss.backward(),
+ * /root/reference/esrgan/train.py:161 with autocast off): `in` and `dy` are blocked fp32 tensors [N][H][units][W][4],
+ * in_units / dy_units / dy_unit_off count 4-channel units, any cout up to 4096; upsample as above, dy_stride2 must
+ * be 0.  v_mfma_f32_32x32x2f32 accumulation, the same fixed-order slab reduction.  Scratch:
+ * sr355_wgrad_f32_workspace_bytes(). */
+size_t sr355_wgrad_f32_workspace_bytes(int cout, int cin, int N, int H, int W);
+int sr355_conv3x3_wgrad_f32(const sr355_wgrad_args *args, void *stream);
 
 /* sr355_conv3x3_wgrad without a workspace: the per-workgroup partial slabs go to a static device array of the
  * library (SR355_STATIC_SCRATCH_BYTES per GPU, held until the process ends); args->workspace_dev / workspace_bytes

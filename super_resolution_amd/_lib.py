@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -30,7 +30,7 @@ EXPORTS = (
     "sr355_packed_weight_bytes", "sr355_pack_weight",
     "sr355_conv3x3_fwd", "sr355_dense_block_fwd",
     "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
-    "sr355_conv3x3_wgrad_static",
+    "sr355_conv3x3_wgrad_static", "sr355_wgrad_f32_workspace_bytes", "sr355_conv3x3_wgrad_f32",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
     "sr355_chain_timing", "sr355_chain_last_ms",
@@ -154,6 +154,9 @@ def lib() -> C.CDLL:
     L.sr355_wgrad_workspace_bytes.restype = sz
     L.sr355_conv3x3_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
     L.sr355_conv3x3_wgrad_static.argtypes = [C.POINTER(WgradArgs), vp]
+    L.sr355_wgrad_f32_workspace_bytes.argtypes = [i, i, i, i, i]
+    L.sr355_wgrad_f32_workspace_bytes.restype = sz
+    L.sr355_conv3x3_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]
     L.sr355_generator_num_convs.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.argtypes = [C.POINTER(GeneratorCfg)]
     L.sr355_generator_packed_bytes.restype = sz

@@ -551,6 +551,43 @@ int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *p, void *stream) {
                            (hipStream_t)stream, p->dy_stride2);
 }
 
+size_t sr355_wgrad_f32_workspace_bytes(int cout, int cin, int N, int H, int W) {
+    if (cout < 1 || cin < 1 || N < 1 || H < 1 || W < 1 || cout > 4096) return 0;
+    return wgrad_f32_workspace_bytes(cout, cin, N, H, W);
+}
+
+int sr355_conv3x3_wgrad_f32(const sr355_wgrad_args *p, void *stream) {
+    const char *who = "conv3x3_wgrad_f32";
+    if (!p) {
+        set_error("%s: args is null", who);
+        return SR355_ERR_INVALID;
+    }
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || p->cout > 4096 || p->cin < 1 || p->dy_stride2 ||
+        (p->upsample != 0 && p->upsample != 1) || (p->upsample && ((p->H | p->W) & 1))) {
+        set_error("%s: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d dy_stride2=%d", who, p->N, p->H, p->W, p->cout,
+                  p->cin, p->upsample, p->dy_stride2);
+        return SR355_ERR_INVALID;
+    }
+    const int Hin = p->H >> p->upsample, Win = p->W >> p->upsample;
+    const size_t in_img = (size_t)Hin * p->in_units * Win * 16, dy_img = (size_t)p->H * p->dy_units * p->W * 16;
+    if (!p->in_dev || !aligned16(p->in_dev) || p->in_bytes < in_img * p->N || (p->cin + 3) / 4 > p->in_units ||
+        !p->dy_dev || !aligned16(p->dy_dev) || p->dy_bytes < dy_img * p->N || p->dy_unit_off < 0 ||
+        p->dy_unit_off + (p->cout + 3) / 4 > p->dy_units) {
+        set_error("%s: input / gradient buffers missing, misaligned, too small or out of range", who);
+        return SR355_ERR_INVALID;
+    }
+    const size_t need = wgrad_f32_workspace_bytes(p->cout, p->cin, p->N, p->H, p->W);
+    if (!p->dw_dev || p->dw_bytes < (size_t)p->cout * p->cin * 9 * 4 || !p->workspace_dev || !aligned16(p->workspace_dev) ||
+        p->workspace_bytes < need) {
+        set_error("%s: dw or scratch missing / too small (this shape needs %zu scratch bytes, %zu available)", who, need,
+                  p->workspace_bytes);
+        return SR355_ERR_INVALID;
+    }
+    return launch_wgrad3x3_f32((const float *)p->in_dev, p->in_units, p->upsample, (const float *)p->dy_dev, p->dy_units,
+                               p->dy_unit_off, p->N, p->H, p->W, p->cout, p->cin, p->scale, p->accumulate, p->dw_dev,
+                               p->db_dev, (float *)p->workspace_dev, (hipStream_t)stream);
+}
+
 // ---- layers around the convs of the discriminator / VGG19, loss reductions ---------------------
 size_t sr355_bn_workspace_bytes(int N, int H, int W, int C) {
     if (N < 1 || H < 1 || W < 1 || C < 8 || (C & 7)) return 0;

@@ -638,6 +638,15 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
     return check_hip(hipGetLastError(), "wgrad reduce batch launch");
 }
 
+// The fixed-order reduction of per-workgroup slabs [chunk][G][9][CO][32] (+ bias rows [G][CO]) on its own: the
+// exact-fp32 weight gradient (wgrad_f32.hip) writes the same slab layout.
+int launch_wgrad_reduce(const float *slabs, float *dw, int cout, int cin, int CO, int G, float scale, int accumulate,
+                        const float *bias_slabs, float *db, hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid_for((size_t)9 * cout * ((cin + 3) / 4) + cout)), dim3(256), 0,
+                       stream, slabs, dw, cout, cin, CO, G, scale, accumulate, bias_slabs, db);
+    return check_hip(hipGetLastError(), "wgrad reduce launch");
+}
+
 // A conv with more than 64 output channels (a multiple of 32): its 32-output slices are the jobs of batched launches
 // (blockIdx.z = slice, all reading the same input), WGRAD_MAX_JOBS slices per launch, each followed by one batched
 // reduction.  One launch per 64 outputs would leave most of the chip idle at the small images such layers have.

@@ -180,6 +180,15 @@ int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int d
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream, int dy_stride2 = 0);
 
+int launch_wgrad_reduce(const float *slabs, float *dw, int cout, int cin, int CO, int G, float scale, int accumulate,
+                        const float *bias_slabs, float *db, hipStream_t stream);
+
+// ---- wgrad_f32.hip: the weight gradient on blocked fp32 tensors (4-channel units), same slab layout ----
+size_t wgrad_f32_workspace_bytes(int cout, int cin, int N, int H, int W);
+int launch_wgrad3x3_f32(const float *in, int in_units, int ups, const float *dy, int dy_units, int dy_unit_off, int N,
+                        int H, int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
+                        hipStream_t stream);
+
 // Device address, on the current device, of the library's static scratch array (SR355_STATIC_SCRATCH_BYTES).
 int wgrad_static_scratch(float **out);
 

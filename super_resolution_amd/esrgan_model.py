@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from . import ops
+from . import fp32_train, ops
 from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB
 
 _PRECISIONS = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32, "f32": DTYPE_F32}
@@ -163,8 +163,8 @@ class ResidualDenseBlock(nn.Module):
         _check_input(x, self.in_channels)
         dtype = _PRECISIONS[self.precision]
         if _records_graph(self, x):
-            if dtype != DTYPE_BF16:
-                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+            if dtype != DTYPE_BF16:        # exact-fp32 training: one autograd node per conv
+                return fp32_train.block_forward(self, x.float(), False)
             return _BlockFunction.apply(x.float().contiguous(), self, *[p for c in self._convs() for p in (c.weight, c.bias)])
         cpu = ops.UNIT_CHANNELS[dtype]
         units = (self.in_channels + 4 * self.growth_channels) // cpu
@@ -191,7 +191,7 @@ class RRDB(nn.Module):
         dtype = _PRECISIONS[self.precision]
         if _records_graph(self, x):
             if dtype != DTYPE_BF16:
-                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+                return fp32_train.block_forward(self, x.float(), True)
             params = [p for r in (self.rdb1, self.rdb2, self.rdb3) for c in r._convs() for p in (c.weight, c.bias)]
             return _BlockFunction.apply(x.float().contiguous(), self, *params)
         cpu = ops.UNIT_CHANNELS[dtype]
@@ -208,7 +208,8 @@ class RRDB(nn.Module):
 
 class GeneratorRRDB(nn.Module):
     """ESRGAN x4 generator.  ``precision`` selects the kernel arithmetic: ``"bf16"`` (bf16 storage,
-    fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path).
+    fp32 accumulation, fp32 residual trunk) or ``"fp32"`` (exact fp32 matrix-core path; it trains too, conv by conv
+    through ``fp32_train``: the accuracy path, several times slower than the bf16 backward).
     ``hr_split`` (bf16 only) carries the bf16 rounding residue of the weights of the four
     HR-side convs, and of the input and weights of conv_first, as extra MFMA terms; their rounding
     otherwise dominates the output error (50.0 dB -> 53.9 dB PSNR against fp32 at +8 % MFMA work).
@@ -328,7 +329,9 @@ class GeneratorRRDB(nn.Module):
         params = self.conv_parameters()
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
             if _PRECISIONS[self.precision] != DTYPE_BF16:
-                raise NotImplementedError("training runs on the bf16 kernels: construct with precision='bf16'")
+                # exact-fp32 training (the reference without autocast): one autograd node per conv, gradients
+                # through autograd's own accumulation
+                return fp32_train.generator_forward(self, xin)
             return _GeneratorFunction.apply(xin, self, None, *_graph_params(self, params))
         N, _c, H, W = xin.shape
         return ops.generator_forward(xin.detach(), self.packed_parameters(True), self.workspace(N, H, W, xin.device),

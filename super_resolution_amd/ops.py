@@ -333,6 +333,36 @@ def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
     return None
 
 
+@torch.library.custom_op("sr355::conv3x3_wgrad_f32", mutates_args=("dw", "db"))
+def conv3x3_wgrad_f32(in_buf: Tensor, cin: int, upsample: int, dy: Tensor, dy_unit_off: int, cout: int, scale: float,
+                      accumulate: int, dw: Tensor, db: Optional[Tensor]) -> None:
+    """Weight / bias gradient of a 3x3 conv on the exact-fp32 path: blocked fp32 input and output gradient
+    ``[N, H, units, W, 4]`` (``dy_unit_off`` in 4-channel units), any number of output channels."""
+    _need_cuda(in_buf, dy, dw, db)
+    if in_buf.dtype != torch.float32 or dy.dtype != torch.float32 or in_buf.dim() != 5 or dy.dim() != 5:
+        raise RuntimeError("conv3x3_wgrad_f32 runs on blocked fp32 tensors [N, H, units, W, 4]")
+    a = WgradArgs()
+    N, H, _U, W, _c = dy.shape
+    a.N, a.H, a.W, a.upsample = int(N), int(H), int(W), int(upsample)
+    a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
+    a.dy_dev, a.dy_bytes, a.dy_units, a.dy_unit_off = dy.data_ptr(), _nbytes(dy), int(dy.shape[2]), int(dy_unit_off)
+    a.cout, a.scale, a.accumulate = int(cout), float(scale), int(accumulate)
+    a.dw_dev, a.dw_bytes, a.db_dev = dw.data_ptr(), _nbytes(dw), _ptr(db)
+    L = _lib.lib()
+    need = L.sr355_wgrad_f32_workspace_bytes(cout, cin, N, H, W)
+    if need == 0:
+        raise RuntimeError("conv3x3_wgrad_f32: unsupported shape")
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
+    a.workspace_dev, a.workspace_bytes = ws.data_ptr(), need
+    with _on(dy.device):
+        check(L.sr355_conv3x3_wgrad_f32(C.byref(a), _stream()), "sr355_conv3x3_wgrad_f32")
+
+
+@conv3x3_wgrad_f32.register_fake
+def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
+    return None
+
+
 def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor,
                       stride: int = 1) -> None:
     """Weight / bias gradient of a conv with any number of output channels.  Up to 64, or any multiple of 32, is one
@@ -757,5 +787,9 @@ maxpool2x2_fwd_now = now(maxpool2x2_fwd)
 maxpool2x2_bwd_now = now(maxpool2x2_bwd)
 loss_fwd_now = now(loss_fwd)
 conv3x3_wgrad_now = now(conv3x3_wgrad)
+conv3x3_wgrad_f32_now = now(conv3x3_wgrad_f32)
+pack_weight_now = now(pack_weight)
+pack_weight_transposed_now = now(pack_weight_transposed)
+pool2x2_sum_now = now(pool2x2_sum)
 to_blocked_now = now(to_blocked)
 from_blocked_now = now(from_blocked)

@@ -13,7 +13,7 @@ CFG = [3, 3, 64, 2, 32, DTYPE_BF16, 1, 1]          # two RRDBs, bf16, weight res
 N, H, W = 2, 9, 33
 
 OPS = ("to_blocked", "from_blocked", "pack_weight", "conv3x3_fwd", "pack_weight_transposed", "pool2x2_sum",
-       "conv3x3_wgrad", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
+       "conv3x3_wgrad", "conv3x3_wgrad_f32", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
        "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step", "dense_block_fwd",
        "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd")
 
@@ -47,6 +47,8 @@ def test_layout_and_conv_ops_under_fake_mode():
         assert torch.ops.sr355.conv3x3_fwd(b, 4, wp, bp, 32, 0.2, 0, None, 0.0, None, 0.0, b, 4, None, None) is None
         dw, db = cuda(32, 20, 3, 3), cuda(32)
         assert torch.ops.sr355.conv3x3_wgrad(b, 20, 0, b, 4, 32, 1.0, 0, dw, db) is None
+        b32 = torch.ops.sr355.to_blocked(x, 16, DTYPE_F32)
+        assert torch.ops.sr355.conv3x3_wgrad_f32(b32, 20, 0, b32, 8, 32, 1.0, 0, dw, db) is None
 
 
 def test_generator_ops_under_fake_mode():
