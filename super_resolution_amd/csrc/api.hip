@@ -110,7 +110,11 @@ static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
     };
     w.x0 = take(P * w.in_units * 16);
     w.bufA = take(P * w.blk_units * 16);
+#ifdef SR355_EXP_ALIAS   /* timing experiments only: wrong results */
+    w.bufB = w.bufA;
+#else
     w.bufB = take(P * w.blk_units * 16);
+#endif
     w.T = take(P * c.num_features * 4);
     w.R = take(P * c.num_features * 4);
     w.F = take(P * c.num_features * 4);
@@ -120,7 +124,7 @@ static Workspace carve(const sr355_generator_cfg &c, int N, int H, int W) {
     w.H3 = take(16 * P * w.nf_units * 16);
     // the chain kernel's per-tile pass counters (+ its error word; a block of its own, a multiple of 16 bytes) and its
     // table of passes: six per dense block, two for trunk_conv
-    w.chain_flag_bytes = ((size_t)N * ((H + 15) / 16) * ((W + 31) / 32) + 1 + 3) / 4 * 16;
+    w.chain_flag_bytes = ((size_t)N * ((H + CHAIN_TILE_ROWS - 1) / CHAIN_TILE_ROWS) * ((W + 31) / 32) + 1 + 3) / 4 * 16;
     w.chain_flags = take(w.chain_flag_bytes);
     w.chain_table = take((size_t)(18 * c.num_blocks + 2) * sizeof(ChainPass));
     w.total = off;
@@ -805,7 +809,7 @@ static bool use_chain(const sr355_generator_cfg *cfg, int N, int H, int W) {
     if (!knob || cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features != 64 || cfg->growth_channels != 32) return false;
     int slots = 0;
     if (chain_resident_workgroups(&slots) || slots < 2) return false;
-    return (long long)N * ((H + 15) / 16) * ((W + 31) / 32) >= slots / 2;
+    return (long long)N * ((H + CHAIN_TILE_ROWS - 1) / CHAIN_TILE_ROWS) * ((W + 31) / 32) >= slots / CHAIN_WG_PER_CU;
 }
 
 // The word the chain kernel raises when a wait gave up, copied back after every chain launch and looked at by the

@@ -53,7 +53,7 @@ constexpr int RSU = 2;           // units per stage
 constexpr int OOB = 0x7fffff00;  // byte offset beyond any descriptor range -> DMA writes zeros
 
 struct ChainGeo {
-    static constexpr int WAVES = 4, NB = 4, CO = 32;
+    static constexpr int WAVES = 4, NB = CHAIN_NB, CO = 32;
     static constexpr int TH = WAVES * NB;                      // 16 rows
     static constexpr int NPIX = (TH + 2) * TWP;
     static constexpr int NIN = RSU * NPIX;
@@ -71,7 +71,7 @@ struct ChainGeo {
     static constexpr int N_READS = 3 + NB + 2;                 // LDS reads of one tap column
     static constexpr int N_MFMA = 3 * NB;                      // MFMAs of one tap column
     static_assert(NWT % 64 == 0, "weight image must be whole wave-instructions");
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    static_assert(CHAIN_WG_PER_CU * LDS_BYTES <= 160 * 1024, "workgroups per CU");
     static_assert(2 * N_MFMA >= N_READS && N_MFMA >= KMAX, "not enough MFMAs to hide the reads / the DMA issue");
 };
 typedef ChainGeo G;
@@ -96,10 +96,19 @@ typedef ChainGeo G;
 //     wrong values (tests/test_gpu_chain.py fails).  Four are inserted.
 typedef int chain_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void chain_store16(const epi_v4u &data, chain_v4i rsrc, int voffset, int soffset) {
+#if defined(SR355_EXP_NOSTORE)      /* timing experiments only: wrong results */
+    asm volatile("s_nop 4\n\ts_nop 3" : : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#elif defined(SR355_EXP_PLAINSTORE)
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3"
+                 :
+                 : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
+                 : "memory");
+#else
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 3"
                  :
                  : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
                  : "memory");
+#endif
 }
 
 // FIRST: the first skip is absent (0), the bf16 activations (1) or an fp32 carrier (2); SECOND: a.res2 is present;
@@ -162,7 +171,7 @@ __device__ __forceinline__ void chain_epilogue_as(const ConvArgs &a, f32x16 (&ac
     // Rows are handled in groups whose skip loads fit the register file beside the accumulators: all four rows at
     // once, or two and two when both skips are present (the second group's loads then wait for the first group's
     // stores: one write-through round trip per pass instead of one per row).
-    constexpr int NBG = (has_r2 && FIRST != 0) ? 2 : NB;
+    constexpr int NBG = (has_r2 && FIRST != 0) ? (NB % 2 == 0 ? 2 : 1) : NB;
 #pragma unroll
     for (int g0 = 0; g0 < NB; g0 += NBG) {
         epi_v2u ra[has_ra ? NBG : 1][4];
@@ -265,7 +274,7 @@ __device__ __forceinline__ void chain_epilogue(const ConvArgs &a, f32x16 (&acc)[
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
+__global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const ChainArgs c) {
     constexpr int WAVES = G::WAVES, NB = G::NB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(4))) const ChainPass cpass_t;   // read through the scalar cache: the table is
@@ -295,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     // at full speed, the other fills its gaps, and both advance at about the same rate.  (Where the pairing does not
     // hold the priorities are merely arbitrary.)
     const bool prio_alternates = (int)blockIdx.x < (nwg >> 1);
-    if (!prio_alternates) __builtin_amdgcn_s_setprio(1);
+    const int prio_class = CHAIN_WG_PER_CU == 3 ? (int)blockIdx.x / ((nwg + 2) / 3) : 0;   // (three per CU: rotation)
+    if (CHAIN_WG_PER_CU == 2 && !prio_alternates) __builtin_amdgcn_s_setprio(1);
     const int n_my = first < n_tiles ? (n_tiles - first + nwg - 1) / nwg : 0;
     const int n_ord = c.n_passes * n_my;          // this workgroup's tasks: pass-major, its tiles within a pass
     if (n_ord == 0) return;
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             if (wave == 0 && p_ + 1 < c.n_passes) SR355_CURSOR_DMA(p_ + 1);                           \
         }                                                                                             \
         const int cout_pad_ = cur_cout_pad;                                                           \
-        const bool new_tile_ = i_ != it_i;                                                            \
+        const bool new_tile_ = i_ != it_i || SR355_EXP_SKIP2_V;                                       \
         if (new_tile_) {                                                                              \
             const int t_ = first + i_ * nwg;                                                          \
             it_tx = t_ % c.tiles_x;                                                                   \
@@ -376,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
                     const bool valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W); \
                     voff[k] = valid ? ((y * c.in_units + u) * W + x) * 16 : OOB;                      \
                 }                                                                                     \
+                if (SR355_EXP_SKIP2_V && p_ % 6 == 5) voff[k] = OOB;                                  \
             } else if (j < G::JTOT) {                                                                 \
                 const int jw = (j - G::NIN_I) * 64 + lane;                                            \
                 const int u = jw / (9 * G::CO);                                                       \
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             const int lo_ = is_in_ ? in_lo : w_lo, hi_ = is_in_ ? in_hi : w_hi;                       \
             const int len_ = is_in_ ? in_len : w_len, so_ = is_in_ ? soff_in_ : soff_w_;              \
             const int dst_ = exists_ ? dst0_ + k * WAVES * 1024 : G::DUMMY_OFF;                       \
-            const int vo_ = (live_ && exists_) ? voff[k] : OOB;                                       \
+            const int vo_ = (live_ && exists_ && !SR355_EXP_NOLOAD_V) ? voff[k] : OOB;                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16, vo_, \
                                                      so_, 0, 0);                                      \
         }                                                                                             \
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         gu32 *f_ = (gu32 *)c.flags + ((size_t)it_n * c.tiles_y + (polls_ ? ty_ : it_ty)) * c.tiles_x + \
                    (polls_ ? tx_ : it_tx);                                                            \
         const unsigned long long t0_ = wall_clock64();                                                \
-        while (!gave_up) {                                                                            \
+        while (!gave_up && !SR355_EXP_NOPOLL_V) {                                                     \
             const unsigned v_ = polls_ ? __hip_atomic_load(f_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; \
             if (__all(!polls_ || v_ >= (unsigned)(NEED))) break;                                      \
             __builtin_amdgcn_s_sleep(2);                                                              \
@@ -464,6 +475,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             else XF[rho] = exp_prev_[rho];                                                            \
         _Pragma("unroll") for (int rho = 0; rho < NB + 2; ++rho) exp_prev_[rho] = XF[rho];            \
     }
+#ifdef SR355_EXP_NOLOAD   /* timing experiments only: every DMA reads out of range (zeros, no fetch) */
+#define SR355_EXP_NOLOAD_V true
+#else
+#define SR355_EXP_NOLOAD_V false
+#endif
+#ifdef SR355_EXP_SKIP2    /* timing experiments only: the second pass of a conv5 fetches no activations */
+#define SR355_EXP_SKIP2_V true
+#else
+#define SR355_EXP_SKIP2_V false
+#endif
+#ifdef SR355_EXP_NOPOLL   /* timing experiments only: wrong results */
+#define SR355_EXP_NOPOLL_V true
+#else
+#define SR355_EXP_NOPOLL_V false
+#endif
 #ifdef SR355_EXP_READS
 #define SR355_EXP_KEEP(KX) ((KX) == 0)
 #else
@@ -512,7 +538,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
     int ct_i = -1, ct_tx = 0, ct_ty = 0, ct_n = 0;
     for (int ord = 0; ord < n_ord; ++ord) {
         const int p = ord / n_my;
-        if (prio_alternates) {   // (measured: per pass beats per stage and per two passes; this parity balances the halves)
+        if (CHAIN_WG_PER_CU == 3) {
+            const int pr = (p + prio_class) % 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        } else if (prio_alternates) {   // (measured: per pass beats per stage and per two passes; this parity balances the halves)
             if (p & 1) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
@@ -586,7 +617,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
             SR355_MMA_FRAGS(wfB, xfB);
             SR355_INTERLEAVE(G::N_READS, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SR355_EXP_NOMFMA2   /* timing experiments only: a third of the MFMAs dropped */
             SR355_MMA_FRAGS(wfA, xfA);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             issue_slot ^= 1;
             slot ^= 1;
@@ -600,10 +633,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_chain(const ChainArgs c) {
         }
         // ---- epilogue of task ord: write-through stores, published at the next stage boundary ----
         CHAIN_T0(te_);
+#ifdef SR355_EXP_NOEPI   /* timing experiments only: wrong results */
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) _Pragma("unroll") for (int e = 0; e < 16; ++e) {
+            asm volatile("" ::"v"(acc[0][nb][e]));
+            acc[0][nb][e] = 0.f;
+        }
+#else
         {
             chain_epilogue(a, acc, smem + G::BIAS_OFF + (ord & 1) * 256, ct_n, ct_ty * G::TH + wave * NB, ct_tx * 32 + r,
                            cb_co, h);
         }
+#endif
         CHAIN_ADD(3, te_);
         pub_tile = (ct_n * c.tiles_y + ct_ty) * c.tiles_x + ct_tx;
         pub_val = (unsigned)(p + 1);
@@ -667,7 +707,7 @@ int chain_resident_workgroups(int *out) {
                       "hipOccupancyMaxActiveBlocksPerMultiprocessor") ||
             check_hip(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute"))
             return;
-        if (per_cu > 2) per_cu = 2;
+        if (per_cu > CHAIN_WG_PER_CU) per_cu = CHAIN_WG_PER_CU;
         slots[dev] = per_cu * cu;
         rc_of[dev] = SR355_OK;
     });

@@ -95,6 +95,14 @@ inline void chain_fill_cursor(ChainPass &ps) {
     ps.cur.need = ps.need, ps.cur.dep_stage = ps.dep_stage, ps.cur.need2 = ps.need2, ps.cur.dep2_stage = ps.dep2_stage;
     ps.cur.pad[0] = ps.cur.pad[1] = ps.cur.pad[2] = ps.cur.pad[3] = 0;
 }
+// Rows a wave computes of the chain kernel's tile (tile = 4 waves x CHAIN_NB rows x 32 pixels) and the workgroups of
+// it a CU holds: 4 rows -> 62 KB of LDS, two per CU; 3 rows -> 51 KB, three per CU.
+#ifndef SR355_CHAIN_NB
+#define SR355_CHAIN_NB 4
+#endif
+constexpr int CHAIN_NB = SR355_CHAIN_NB;
+constexpr int CHAIN_TILE_ROWS = 4 * CHAIN_NB;
+constexpr int CHAIN_WG_PER_CU = CHAIN_NB >= 4 ? 2 : 3;
 struct ChainArgs {
     const ChainPass *passes;   // device memory, written before the launch
     int n_passes;
