@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 12
+#define SR355_ABI_VERSION 13
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -249,6 +249,13 @@ int sr355_bn_lrelu_bwd(const float *x_f32_dev, size_t x_bytes, const void *dy_ac
                        const float *save_mean_dev, const float *save_rstd_dev, float lrelu_slope, int training,
                        void *dx_act_dev, size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma_dev,
                        float *dbeta_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* nn.PixelShuffle(2) on the blocked layout (the sub-pixel stages of CycleGAN/CycleGAN_w_v1/CycleGAN.py:117-129,
+ * condtional VAE/model.py:118-133): src [N][H][4*c_out/c][W][c] -> dst [N][2H][c_out/c][2W][c],
+ * dst[n][2y+dy][ch][2x+dx] = src[n][y][4*ch + 2*dy + dx][x]; c = channels per 16-byte unit of `dtype`, c_out a
+ * multiple of it.  inverse = 1 runs the other way (src is the 2H x 2W tensor): the gradient of the forward op. */
+int sr355_pixel_shuffle2(const void *src_dev, size_t src_bytes, int N, int H, int W, int c_out, int dtype, int inverse,
+                         void *dst_dev, size_t dst_bytes, void *stream);
 
 /* ---- nn.MaxPool2d(2, 2) on blocked bf16 (vgg19.features' pooling layers, esrgan_model.py:93-98) ----
  * in [N][H][units][W] -> out [N][H/2][units][W/2] (an odd trailing row / column is dropped).  The backward pass

@@ -249,6 +249,75 @@ def conv_bn_act(x: Tensor, conv, bn, slope: float) -> Tensor:
     return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn, slope, int(conv.stride[0]))
 
 
+def _blocked_to_f32_layout(t: Tensor) -> Tensor:
+    """blocked bf16 [N, H, C/8, W, 8] -> fp32 layout [N, H, C/4, W, 4]."""
+    N, H, U, W, _ = t.shape
+    return t.reshape(N, H, U, W, 2, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, 2 * U, W, 4).float()
+
+
+def _f32_layout_to_blocked(t: Tensor) -> Tensor:
+    """fp32 layout [N, H, C/4, W, 4] -> blocked bf16 [N, H, C/8, W, 8]."""
+    N, H, Q, W, _ = t.shape
+    return t.reshape(N, H, Q // 2, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, Q // 2, W, 8).to(torch.bfloat16).contiguous()
+
+
+class _ConvAdd(torch.autograd.Function):
+    """``trunk + conv3x3(x)`` as ONE launch: the conv's epilogue reads the fp32 trunk, adds, and writes the new fp32
+    trunk together with its bf16 copy (what the next conv reads).  The residual step of
+    /root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py:97-100 without a separate add or layout pass."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor, trunk: Tensor):
+        cout, cin = int(weight.shape[0]), int(weight.shape[1])
+        if x.dtype != torch.bfloat16 or x.dim() != 5 or not x.is_contiguous():
+            raise RuntimeError("conv3x3_add: expected a contiguous blocked bf16 tensor [N, H, units, W, 8]")
+        N, H, U, W, _ = x.shape
+        if cout % 16 or trunk.dtype != torch.float32 or tuple(trunk.shape) != (N, H, cout // 4, W, 4):
+            raise RuntimeError("conv3x3_add: the trunk must be fp32 [N, H, cout/4, W, 4] with cout a multiple of 16")
+        if U < units_for(cin):
+            raise RuntimeError(f"conv3x3_add: input has {U} units, the weight needs {units_for(cin)}")
+        wp, bp = _packs_of(weight).forward_pack(weight, bias)
+        new_trunk = torch.empty_like(trunk, memory_format=torch.contiguous_format)
+        act = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=x.device)
+        ops.conv3x3_fwd_now(x, units_for(cin), wp, bp, cout, 1.0, 0, trunk.contiguous(), 1.0, None, 0.0, act, 0, new_trunk,
+                            None)
+        ctx.save_for_backward(x, weight, bias)
+        return new_trunk, act
+
+    @staticmethod
+    def backward(ctx, g_trunk, g_act):
+        x, weight, bias = ctx.saved_tensors
+        total = g_trunk
+        if g_act is not None:
+            ga = _blocked_to_f32_layout(g_act)
+            total = ga if total is None else total + ga
+        dx, dw, db = _conv_backward(x, weight, bias, _f32_layout_to_blocked(total), 1, ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, total
+
+
+def conv3x3_add(x: Tensor, weight: Tensor, bias: Tensor, trunk: Tensor) -> Tuple[Tensor, Tensor]:
+    """``trunk + conv3x3(x)`` in one launch: returns (new fp32 trunk ``[N, H, C/4, W, 4]``, its blocked bf16 copy)."""
+    return _ConvAdd.apply(x, weight, bias, trunk)
+
+
+class _PixelShuffle2(torch.autograd.Function):
+    """``nn.PixelShuffle(2)`` on a blocked tensor, one HIP kernel each way (the gradient is the inverse permutation)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor) -> Tensor:
+        return ops.pixel_shuffle2_now(x.contiguous(), False)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return ops.pixel_shuffle2_now(g.contiguous(), True)
+
+
+def pixel_shuffle2(x: Tensor) -> Tensor:
+    """``nn.PixelShuffle(2)``: blocked ``[N, H, 4U, W, c]`` -> ``[N, 2H, U, 2W, c]`` (bf16 or fp32 units)."""
+    return _PixelShuffle2.apply(x)
+
+
 def f32_as_nchw(y: Tensor) -> Tensor:
     """View of an fp32 conv output [N, H, C/4, W, 4] as [N, C, H, W] (no copy)."""
     N, H, Q, W, c = y.shape

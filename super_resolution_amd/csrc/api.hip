@@ -667,6 +667,21 @@ int sr355_maxpool2x2_fwd(const void *in_act, size_t in_bytes, int N, int H, int 
     return launch_maxpool2x2_fwd(in_act, N, H, W, units, out_act, (hipStream_t)stream);
 }
 
+int sr355_pixel_shuffle2(const void *src, size_t src_bytes, int N, int H, int W, int c_out, int dtype, int inverse, void *dst,
+                         size_t dst_bytes, void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (cpu < 0 || N < 1 || H < 1 || W < 1 || c_out < cpu || c_out % cpu || (long long)N * H * W * c_out > 0x3fffffffLL) {
+        set_error("pixel_shuffle2: bad arguments (N=%d H=%d W=%d c_out=%d dtype=%d)", N, H, W, c_out, dtype);
+        return SR355_ERR_INVALID;
+    }
+    const size_t bytes = (size_t)N * H * W * 4 * c_out * (16 / cpu);     // both tensors hold the same elements
+    if (!src || !dst || !aligned16(src) || !aligned16(dst) || src_bytes < bytes || dst_bytes < bytes) {
+        set_error("pixel_shuffle2: buffers missing, misaligned or smaller than %zu bytes", bytes);
+        return SR355_ERR_INVALID;
+    }
+    return launch_pixel_shuffle2(src, N, H, W, c_out, dtype, inverse ? 1 : 0, dst, (hipStream_t)stream);
+}
+
 int sr355_maxpool2x2_bwd(const void *in_act, size_t in_bytes, const void *dy_act, size_t dy_bytes, int N, int H, int W,
                          int units, void *dx_act, size_t dx_bytes, void *stream) {
     if (N < 1 || H < 1 || W < 1 || units < 1 || !in_act || !aligned16(in_act) || !dy_act || !aligned16(dy_act) ||

@@ -425,6 +425,69 @@ int launch_maxpool2x2_bwd(const void *in, const void *dy, int N, int H, int W, i
     return check_hip(hipGetLastError(), "maxpool2x2_bwd launch");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// nn.PixelShuffle(2) on the blocked layout (the sub-pixel stages of /root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py:
+// 117-129 and /root/reference/condtional VAE/model.py:118-133): in [N][H][4C/c][W][c] -> out [N][2H][C/c][2W][c] with
+// out[n][2y+dy][ch][2x+dx] = in[n][y][4 ch + 2 dy + dx][x]; c = 8 (bf16) or 4 (fp32) channels per 16-byte unit.
+// One thread per 16-byte unit of the LARGER-resolution tensor; INVERSE scatters the other way (the gradient).
+template <typename T, bool INVERSE>
+__global__ void pixel_shuffle2_kernel(const T *__restrict__ src, T *__restrict__ dst, int H, int W, int Uo, size_t n_units) {
+    constexpr int CPU = 16 / sizeof(T);
+    const int Ho = 2 * H, Wo = 2 * W, Ui = 4 * Uo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_units; i += (size_t)gridDim.x * blockDim.x) {
+        // (n, yo, uo, xo): a unit of the high-resolution tensor
+        const int xo = (int)(i % Wo);
+        size_t t = i / Wo;
+        const int uo = (int)(t % Uo);
+        t /= Uo;
+        const int yo = (int)(t % Ho);
+        const size_t n = t / Ho;
+        const int y = yo >> 1, x = xo >> 1, off = 2 * (yo & 1) + (xo & 1);
+        T v[CPU];
+        if (INVERSE) {
+            const uint4 raw = reinterpret_cast<const uint4 *>(src)[i];
+            __builtin_memcpy(v, &raw, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < CPU; ++j) {
+            const int ci = 4 * (uo * CPU + j) + off;       // channel of the low-resolution tensor
+            const size_t lo = ((((n * H + y) * Ui + ci / CPU) * W + x) * CPU) + ci % CPU;
+            if (INVERSE) dst[lo] = v[j];
+            else v[j] = src[lo];
+        }
+        if (!INVERSE) {
+            uint4 pk;
+            __builtin_memcpy(&pk, v, 16);
+            reinterpret_cast<uint4 *>(dst)[i] = pk;
+        }
+    }
+}
+
+int launch_pixel_shuffle2(const void *src, int N, int H, int W, int c_out, int dtype, int inverse, void *dst,
+                          hipStream_t stream) {
+    const int cpu = unit_channels(dtype);
+    const int Uo = c_out / cpu;
+    const size_t n_units = (size_t)N * 2 * H * Uo * 2 * W;
+    if (n_units == 0) return SR355_OK;
+    const dim3 grid(aux_grid(n_units)), block(AUX_THREADS);
+    if (dtype == SR355_DTYPE_BF16) {
+        if (inverse)
+            hipLaunchKernelGGL((pixel_shuffle2_kernel<__bf16, true>), grid, block, 0, stream, (const __bf16 *)src,
+                               (__bf16 *)dst, H, W, Uo, n_units);
+        else
+            hipLaunchKernelGGL((pixel_shuffle2_kernel<__bf16, false>), grid, block, 0, stream, (const __bf16 *)src,
+                               (__bf16 *)dst, H, W, Uo, n_units);
+    } else {
+        if (inverse)
+            hipLaunchKernelGGL((pixel_shuffle2_kernel<float, true>), grid, block, 0, stream, (const float *)src,
+                               (float *)dst, H, W, Uo, n_units);
+        else
+            hipLaunchKernelGGL((pixel_shuffle2_kernel<float, false>), grid, block, 0, stream, (const float *)src,
+                               (float *)dst, H, W, Uo, n_units);
+    }
+    return check_hip(hipGetLastError(), "pixel_shuffle2 launch");
+}
+
 int loss_parts(size_t n) {
     const size_t b = (n / 4 + AUX_THREADS - 1) / AUX_THREADS;
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));

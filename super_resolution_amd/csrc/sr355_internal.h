@@ -212,6 +212,8 @@ int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_uni
                         float *workspace, hipStream_t stream);
 int launch_maxpool2x2_fwd(const void *in, int N, int H, int W, int U, void *out, hipStream_t stream);
 int launch_maxpool2x2_bwd(const void *in, const void *dy, int N, int H, int W, int U, void *dx, hipStream_t stream);
+int launch_pixel_shuffle2(const void *src, int N, int H, int W, int c_out, int dtype, int inverse, void *dst,
+                          hipStream_t stream);
 int loss_parts(size_t n);
 int launch_loss(const float *a, const float *b, float b_const, size_t n, int mode, float *loss, float *grad,
                 float *workspace, hipStream_t stream);

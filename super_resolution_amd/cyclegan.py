@@ -5,12 +5,12 @@ v2 script, CycleGAN_w_v2/CycleGAN2.py:102-150, defines the same network): same c
 ``state_dict`` keys (``conv1.0.*``, ``res_blocks.N.conv{1,2}.*``, ``up{1,2}.0.*``, ``conv_out.*``), NCHW fp32 in and
 out, trainable through autograd.  Every 3x3 convolution — the residual blocks and the two sub-pixel stages, 97 % of
 the FLOPs — runs on the HIP kernels of ``conv_core`` (bf16 operands, fp32 accumulation) with ReLU fused as a
-LeakyReLU of slope 0; the residual trunk is carried in fp32 beside the bf16 copy the next convolution reads.  The two
-7x7 convolutions, PixelShuffle and tanh stay on stock PyTorch-ROCm.
+LeakyReLU of slope 0; the residual trunk is carried in fp32 beside the bf16 copy the next convolution reads, both written by
+the epilogue of a block's second conv (which adds the skip); PixelShuffle is a HIP kernel on the blocked layout.  The
+two 7x7 convolutions and tanh stay on stock PyTorch-ROCm.
 """
 import torch
 from torch import Tensor, nn
-import torch.nn.functional as F
 
 from . import conv_core as cc
 
@@ -27,12 +27,6 @@ def _nchw_to_f32(v: Tensor) -> Tensor:
     return v.view(N, C // 4, 4, H, W).permute(0, 3, 1, 4, 2).contiguous()
 
 
-def _f32_to_blocked(t: Tensor) -> Tensor:
-    """fp32 layout [N, H, C/4, W, 4] -> blocked bf16 [N, H, C/8, W, 8] (what the next convolution reads)."""
-    N, H, Q, W, _ = t.shape
-    return t.view(N, H, Q // 2, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, Q // 2, W, 8).to(torch.bfloat16)
-
-
 class ResidualBlock(nn.Module):
     """CycleGAN.py:89-100 — ``x + conv2(relu(conv1(x)))``."""
 
@@ -47,9 +41,9 @@ class ResidualBlock(nn.Module):
     def _run(self, xb: Tensor, trunk: Tensor):
         """(blocked bf16 x, fp32 x) -> the same pair for the block's output."""
         h = cc.conv3x3(xb, self.conv1.weight, self.conv1.bias, 0.0)              # ReLU fused
-        y = cc.conv3x3(h, self.conv2.weight, self.conv2.bias, 1.0, f32_out=True)
-        trunk = trunk + y
-        return _f32_to_blocked(trunk), trunk
+        # the skip is added in conv2's epilogue, which writes the fp32 trunk and its bf16 copy: one launch
+        trunk, xb = cc.conv3x3_add(h, self.conv2.weight, self.conv2.bias, trunk)
+        return xb, trunk
 
     def forward(self, x: Tensor) -> Tensor:
         _need_cuda(x, "ResidualBlock")
@@ -84,8 +78,7 @@ class GeneratorSR(nn.Module):
             xb, trunk = block._run(xb, trunk)
         for up in (self.up1, self.up2):
             conv = up[0]
-            # ReLU commutes with the pixel shuffle: fused into the convolution as slope 0; the shuffle moves bf16
-            y = cc.conv3x3(xb, conv.weight, conv.bias, 0.0)
-            v = F.pixel_shuffle(cc.blocked_as_nchw(y), 2)
-            xb = cc.nchw_as_blocked(v)
-        return self.tanh(self.conv_out(v.float()))
+            # ReLU commutes with the pixel shuffle: fused into the convolution as slope 0; the shuffle is one HIP
+            # kernel on the blocked layout
+            xb = cc.pixel_shuffle2(cc.conv3x3(xb, conv.weight, conv.bias, 0.0))
+        return self.tanh(self.conv_out(cc.from_blocked(xb, self.conv_out.in_channels)))

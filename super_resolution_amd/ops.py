@@ -452,6 +452,36 @@ def _(x_f32, dy_act, gamma, beta, save_mean, save_rstd, slope, training, dx_act,
     return None
 
 
+@torch.library.custom_op("sr355::pixel_shuffle2", mutates_args=())
+def pixel_shuffle2(x: Tensor, inverse: bool = False) -> Tensor:
+    """``nn.PixelShuffle(2)`` of a blocked tensor ``[N, H, 4U, W, c]`` -> ``[N, 2H, U, 2W, c]`` (bf16 or fp32 units);
+    ``inverse`` maps ``[N, 2H, U, 2W, c]`` back to ``[N, H, 4U, W, c]`` (its gradient)."""
+    _need_cuda(x)
+    if x.dim() != 5 or x.dtype not in _CODE or x.shape[4] != UNIT_CHANNELS[_CODE[x.dtype]]:
+        raise RuntimeError("pixel_shuffle2 runs on blocked bf16 / fp32 tensors [N, H, units, W, c]")
+    N, Hx, Ux, Wx, c = (int(v) for v in x.shape)
+    if inverse:
+        if Hx % 2 or Wx % 2:
+            raise RuntimeError("pixel_shuffle2 (inverse): height and width must be even")
+        H, W, Uo = Hx // 2, Wx // 2, Ux
+        out = torch.empty((N, H, 4 * Uo, W, c), dtype=x.dtype, device=x.device)
+    else:
+        if Ux % 4:
+            raise RuntimeError("pixel_shuffle2: the unit count must be a multiple of 4")
+        H, W, Uo = Hx, Wx, Ux // 4
+        out = torch.empty((N, 2 * H, Uo, 2 * W, c), dtype=x.dtype, device=x.device)
+    with _on(x.device):
+        check(_lib.lib().sr355_pixel_shuffle2(x.data_ptr(), _nbytes(x), N, H, W, Uo * c, _CODE[x.dtype], int(inverse),
+                                              out.data_ptr(), _nbytes(out), _stream()), "sr355_pixel_shuffle2")
+    return out
+
+
+@pixel_shuffle2.register_fake
+def _(x, inverse=False):
+    N, Hx, Ux, Wx, c = x.shape
+    return x.new_empty((N, Hx // 2, 4 * Ux, Wx // 2, c) if inverse else (N, 2 * Hx, Ux // 4, 2 * Wx, c))
+
+
 @torch.library.custom_op("sr355::maxpool2x2_fwd", mutates_args=())
 def maxpool2x2_fwd(x: Tensor) -> Tensor:
     """nn.MaxPool2d(2, 2) on a blocked bf16 tensor ``[N, H, U, W, 8]`` -> ``[N, H//2, U, W//2, 8]``."""
@@ -784,6 +814,7 @@ conv3x3_fwd_now = now(conv3x3_fwd)
 bn_lrelu_fwd_now = now(bn_lrelu_fwd)
 bn_lrelu_bwd_now = now(bn_lrelu_bwd)
 maxpool2x2_fwd_now = now(maxpool2x2_fwd)
+pixel_shuffle2_now = now(pixel_shuffle2)
 maxpool2x2_bwd_now = now(maxpool2x2_bwd)
 loss_fwd_now = now(loss_fwd)
 conv3x3_wgrad_now = now(conv3x3_wgrad)

@@ -72,3 +72,57 @@ def test_generator_sr_default_config_and_block():
         w1, b1, w2, b2 = (t.detach().cpu() for t in (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias))
         want = xb + F.conv2d(F.relu(F.conv2d(xb, w1, b1, padding=1)), w2, b2, padding=1)
     assert rel_l2(got, want) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 64, 5, 7), (1, 16, 1, 1), (3, 32, 9, 33)])
+def test_pixel_shuffle_on_the_blocked_layout_is_nn_pixel_shuffle(dtype, shape):
+    """The HIP permutation against nn.PixelShuffle(2) on the NCHW view, bit for bit, both directions, and as the
+    gradient of each other through autograd."""
+    from super_resolution_amd import conv_core as cc, ops
+    N, C, H, W = shape                                    # C = channels after the shuffle
+    cpu = 8 if dtype == torch.bfloat16 else 4
+    if C % cpu:
+        pytest.skip("channel count below one unit")
+    x = torch.randn(N, 4 * C, H, W, generator=torch.Generator().manual_seed(5)).to(dtype)
+    blocked = x.view(N, 4 * C // cpu, cpu, H, W).permute(0, 3, 1, 4, 2).contiguous().to(DEV)
+    got = ops.pixel_shuffle2(blocked)
+    assert got.shape == (N, 2 * H, C // cpu, 2 * W, cpu)
+    want = torch.nn.functional.pixel_shuffle(x.float(), 2)
+    back = got.permute(0, 2, 4, 1, 3).reshape(N, C, 2 * H, 2 * W).float().cpu()
+    assert torch.equal(back, want)
+    assert torch.equal(ops.pixel_shuffle2(got, True), blocked)
+    leaf = blocked.float().requires_grad_(True)
+    out = cc.pixel_shuffle2(leaf.to(dtype))
+    r = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).to(dtype).to(DEV)
+    out.backward(r)
+    assert torch.equal(leaf.grad.to(dtype), ops.pixel_shuffle2(r, True))
+
+
+def test_residual_conv_with_the_skip_in_its_epilogue():
+    """conv3x3_add = trunk + conv3x3(x): both outputs and all three gradients against autograd on the same operands."""
+    from super_resolution_amd import conv_core as cc
+    gen = torch.Generator().manual_seed(21)
+    N, C, H, W = 2, 64, 9, 13
+    w = (torch.randn(C, C, 3, 3, generator=gen) * 0.05).to(DEV).requires_grad_(True)
+    b = (torch.randn(C, generator=gen) * 0.1).to(DEV).requires_grad_(True)
+    x0, t0 = torch.randn(N, C, H, W, generator=gen), torch.randn(N, C, H, W, generator=gen)
+    x = x0.to(DEV).requires_grad_(True)
+    trunk_nchw = t0.to(DEV).requires_grad_(True)
+    trunk = trunk_nchw.view(N, C // 4, 4, H, W).permute(0, 3, 1, 4, 2).contiguous()
+    new_trunk, act = cc.conv3x3_add(cc.to_blocked(x), w, b, trunk)
+    r1 = torch.randn(N, C, H, W, generator=gen).to(DEV)
+    r2 = torch.randn(N, C, H, W, generator=gen).to(DEV)
+    (cc.f32_as_nchw(new_trunk) * r1).sum().backward(retain_graph=True)
+    (cc.from_blocked(act, C) * r2).sum().backward()
+    F = torch.nn.functional
+    xr = x0.to(torch.bfloat16).float().requires_grad_(True)
+    wr = w.detach().cpu().to(torch.bfloat16).float().requires_grad_(True)
+    br, tr = b.detach().cpu().clone().requires_grad_(True), t0.clone().requires_grad_(True)
+    ref = tr + F.conv2d(xr, wr, br, padding=1)
+    assert (cc.f32_as_nchw(new_trunk).detach().cpu() - ref.detach()).abs().max().item() < 1e-4
+    assert torch.equal(cc.from_blocked(act, C).detach().cpu(), cc.f32_as_nchw(new_trunk).detach().cpu().to(torch.bfloat16).float())
+    (ref * (r1.cpu() + r2.cpu().to(torch.bfloat16).float())).sum().backward()
+    assert rel_l2(trunk_nchw.grad.cpu(), tr.grad) < 1e-6
+    assert rel_l2(x.grad.cpu(), xr.grad) < 1e-2          # the conv's incoming gradient is stored in bf16
+    assert rel_l2(w.grad.cpu(), wr.grad) < 1e-2 and rel_l2(b.grad.cpu(), br.grad) < 1e-2

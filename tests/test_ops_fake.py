@@ -15,7 +15,7 @@ N, H, W = 2, 9, 33
 OPS = ("to_blocked", "from_blocked", "pack_weight", "conv3x3_fwd", "pack_weight_transposed", "pool2x2_sum",
        "conv3x3_wgrad", "conv3x3_wgrad_f32", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
        "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step", "dense_block_fwd",
-       "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd")
+       "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd", "pixel_shuffle2")
 
 
 def test_every_op_is_registered_with_a_fake():
@@ -94,6 +94,9 @@ def test_auxiliary_layer_ops_under_fake_mode():
         assert y.shape == (2, 4, 4, 3, 8) and y.dtype == torch.bfloat16 and y.device.type == "cuda"
         dx = torch.ops.sr355.maxpool2x2_bwd(x, y)
         assert dx.shape == x.shape and dx.dtype == torch.bfloat16
+        ps = torch.ops.sr355.pixel_shuffle2(x)
+        assert ps.shape == (2, 18, 1, 14, 8) and ps.dtype == torch.bfloat16
+        assert torch.ops.sr355.pixel_shuffle2(ps, True).shape == x.shape
         a, b = cuda(3, 5, 7), cuda(3, 5, 7)
         for other, want in ((b, True), (None, False)):
             loss, grad = torch.ops.sr355.loss_fwd(a, other, 1.0, 1, want)
