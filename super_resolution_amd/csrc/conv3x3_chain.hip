@@ -98,6 +98,11 @@ typedef int chain_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void chain_store16(const epi_v4u &data, chain_v4i rsrc, int voffset, int soffset) {
 #if defined(SR355_EXP_NOSTORE)      /* timing experiments only: wrong results */
     asm volatile("s_nop 4\n\ts_nop 3" : : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#elif defined(SR355_EXP_NTSTORE)    /* timing experiment: write-through and non-temporal */
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen sc1 nt\n\ts_nop 3"
+                 :
+                 : "v"(data), "v"(voffset), "s"(rsrc), "s"(soffset)
+                 : "memory");
 #elif defined(SR355_EXP_PLAINSTORE)
     asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3"
                  :
@@ -423,8 +428,12 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
             const int len_ = is_in_ ? in_len : w_len, so_ = is_in_ ? soff_in_ : soff_w_;              \
             const int dst_ = exists_ ? dst0_ + k * WAVES * 1024 : G::DUMMY_OFF;                       \
             const int vo_ = (live_ && exists_ && !SR355_EXP_NOLOAD_V) ? voff[k] : OOB;                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16, vo_, \
-                                                     so_, 0, 0);                                      \
+            if (all_in_ && SR355_EXP_IN_AUX != 0)      /* (folds after unrolling) */                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16,  \
+                                                         vo_, so_, 0, SR355_EXP_IN_AUX);              \
+            else                                                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16,  \
+                                                         vo_, so_, 0, 0);                             \
         }                                                                                             \
     }
 
@@ -475,6 +484,9 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
             else XF[rho] = exp_prev_[rho];                                                            \
         _Pragma("unroll") for (int rho = 0; rho < NB + 2; ++rho) exp_prev_[rho] = XF[rho];            \
     }
+#ifndef SR355_EXP_IN_AUX   /* cache-policy bits of the activation loads (timing experiments: 2 = nt, 1 = sc0, 16 = sc1) */
+#define SR355_EXP_IN_AUX 0
+#endif
 #ifdef SR355_EXP_NOLOAD   /* timing experiments only: every DMA reads out of range (zeros, no fetch) */
 #define SR355_EXP_NOLOAD_V true
 #else
