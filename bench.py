@@ -377,6 +377,27 @@ def strong_scaling(net, dev, world, dist, B, H, W, steps):
             "scaling": "strong", "global_batch": B, "batch_per_gpu": B // world}
 
 
+def collective_rates(dev, world, dist, reps=10):
+    """The mean of the generator's 66.8 MB flat gradient buffer over the ranks, both ways the library can run it: one
+    RCCL all-reduce, and the direct reduce-scatter + all-gather (two all-to-all exchanges, ddp.direct_mean_)."""
+    from super_resolution_amd import ddp
+    n = 16_697_987
+    buf = torch.randn(n, device=dev)
+    out = {"floats": n, "world": world}
+    for alg in ("all_reduce", "direct"):
+        for _ in range(2):
+            ddp.all_reduce_mean(buf, None, alg)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ddp.all_reduce_mean(buf, None, alg)
+        torch.cuda.synchronize()
+        sec = _max_over_ranks((time.perf_counter() - t0) / reps, dev, dist)
+        out[alg] = {"ms": round(sec * 1e3, 3), "algorithmic_GBps_per_rank": round(2 * (world - 1) / world * 4 * n / sec / 1e9, 1)}
+    return out
+
+
 def _max_over_ranks(seconds, dev, dist):
     # RCCL reduces device tensors; the gloo rehearsal reduces on the host
     t = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -637,6 +658,8 @@ def main():
                 if world > 1:
                     print(f"[bench rank {rank}] strong scaling", file=sys.stderr, flush=True)
                     line["strong_scaling"] = strong_scaling(net, dev, world, dist, B, H, W, max(5, args.steps // 2))
+                    print(f"[bench rank {rank}] gradient mean, both algorithms", file=sys.stderr, flush=True)
+                    line["gradient_mean_over_ranks"] = collective_rates(dev, world, dist)
                     print(f"[bench rank {rank}] other configurations", file=sys.stderr, flush=True)
                 others = other_configs(net, dev, world, rank, dist)
                 if rank == 0:

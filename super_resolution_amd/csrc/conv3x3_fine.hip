@@ -38,6 +38,12 @@ extern unsigned long long *g_conv_trace;
 #define SR355_SSTAMP(K)
 #endif
 
+#ifdef SR355_EXP_NOWEIGHTS   /* timing experiment (wrong results): no weight traffic, as if the weights were resident */
+#define SR355_EXP_NOWEIGHTS_V true
+#else
+#define SR355_EXP_NOWEIGHTS_V false
+#endif
+
 namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int lo_ = is_in_ ? in_lo : w_lo, hi_ = is_in_ ? in_hi : w_hi;                       \
             const int len_ = is_in_ ? in_len : w_len, so_ = is_in_ ? soff_in_ : soff_w_;              \
             const int dst_ = exists_ ? dst0_ + k * WAVES * 1024 : G::DUMMY_OFF;                       \
-            const int vo_ = (live_ && exists_) ? voff[k] : OOB;                                       \
+            const int vo_ = (live_ && exists_ && !(SR355_EXP_NOWEIGHTS_V && !is_in_)) ? voff[k] : OOB; \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16, vo_, \
                                                      so_, 0, 0);                                      \
         }                                                                                             \

@@ -67,10 +67,18 @@ def plan_buckets(slices: Sequence[Tuple[int, int]], bucket_floats: int) -> List[
 
 
 def reduce_in_buckets(flat: Tensor, buckets: Sequence[Tuple[int, int, int, int]],
-                      run_phases: Callable[[int, int], None], group=None) -> None:
+                      run_phases: Callable[[int, int], None], group=None, algorithm: str = "all_reduce") -> None:
     """Run the phase groups in order; after each, start the all-reduce (mean) of its slice and go on."""
     import torch.distributed as dist
 
+    if algorithm == "direct":
+        pending = []
+        for pb, pe, lo, hi in buckets:
+            run_phases(pb, pe)
+            pending.append(PendingMean(flat[lo:hi], group, "direct"))
+        for p in pending:
+            p.wait()
+        return
     world = dist.get_world_size(group)
     avg = dist.get_backend(group) == "nccl"
     handles = []
@@ -93,13 +101,74 @@ def reduce_in_buckets(flat: Tensor, buckets: Sequence[Tuple[int, int, int, int]]
             view.div_(world)
 
 
-class PendingMean:
-    """An in-place mean over the ranks of a group that has been started and not yet waited for."""
+_COMM_STREAMS = {}
 
-    def __init__(self, t: Tensor, group=None):
+
+def _comm_stream(device: torch.device) -> "torch.cuda.Stream":
+    """One side stream per device for collectives that are chains of operations (kept for the life of the process)."""
+    s = _COMM_STREAMS.get(device)
+    if s is None:
+        s = _COMM_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def direct_mean_(buf: Tensor, group=None) -> None:
+    """In-place mean of the flat tensor ``buf`` over the ranks of ``group`` as a direct reduce-scatter + all-gather:
+    two all-to-all exchanges.  In the first every rank sends chunk j of its buffer to rank j (all peers at once: on a
+    fully connected xGMI node every link carries 1/world of the buffer, where a ring pushes 2 (world-1)/world of it
+    through each link in turn); rank j adds the world chunks it now holds in rank order and divides; in the second
+    every rank sends its reduced chunk to all peers.  Each element is reduced on exactly one rank in a fixed order, so
+    all ranks end with the same bits.  Blocking with respect to the current stream / the calling thread."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = buf.numel()
+    if world == 1 or n == 0:
+        return
+    flat = buf.view(-1)
+    chunk = -(-n // world)
+    if chunk * world == n:
+        send = flat
+    else:
+        send = flat.new_zeros(chunk * world)
+        send[:n].copy_(flat)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    parts = recv.view(world, chunk)
+    red = parts[0].clone()
+    for r in range(1, world):
+        red.add_(parts[r])
+    red.div_(world)
+    dist.all_to_all_single(recv, red.repeat(world), group=group)
+    flat.copy_(recv[:n])
+
+
+class PendingMean:
+    """An in-place mean over the ranks of a group that has been started and not yet waited for.  ``algorithm``:
+    ``"all_reduce"`` (one RCCL all-reduce, the default) or ``"direct"`` (``direct_mean_`` on a side stream)."""
+
+    def __init__(self, t: Tensor, group=None, algorithm: str = "all_reduce"):
         import torch.distributed as dist
+        if algorithm not in ("all_reduce", "direct"):
+            raise ValueError("algorithm must be 'all_reduce' or 'direct'")
         self.t, self.world = t, dist.get_world_size(group)
         self.host = None
+        self.event = None
+        if algorithm == "direct":
+            self.handle, self.avg = None, True
+            if dist.get_backend(group) == "nccl":
+                # the chain (exchange, add, exchange, copy) runs on a side stream behind what the caller's stream has
+                # enqueued so far; wait() makes the caller's stream wait for its end
+                side = _comm_stream(t.device)
+                side.wait_stream(torch.cuda.current_stream(t.device))
+                t.record_stream(side)
+                with torch.cuda.stream(side):
+                    direct_mean_(t, group)
+                    self.event = torch.cuda.Event()
+                    self.event.record(side)
+            else:
+                self.host = t.cpu() if t.is_cuda else t
+                direct_mean_(self.host, group)
+            return
         if dist.get_backend(group) == "nccl":
             # RCCL runs the collective on its own stream; wait() makes the caller's stream (not the host) wait for it
             self.handle = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True)
@@ -112,6 +181,12 @@ class PendingMean:
             self.avg = False
 
     def wait(self) -> None:
+        if self.handle is None:          # the direct form
+            if self.event is not None:
+                torch.cuda.current_stream(self.t.device).wait_event(self.event)
+            elif self.host is not self.t:
+                self.t.copy_(self.host)
+            return
         self.handle.wait()
         if not self.avg:
             self.host.div_(self.world)
@@ -119,15 +194,16 @@ class PendingMean:
                 self.t.copy_(self.host)
 
 
-def start_all_reduce_mean(t: Tensor, group=None) -> PendingMean:
+def start_all_reduce_mean(t: Tensor, group=None, algorithm: str = "all_reduce") -> PendingMean:
     """Start the in-place mean of ``t`` over the ranks of ``group`` and return at once; kernels enqueued before
     ``wait()`` on the returned object overlap with the collective."""
-    return PendingMean(t, group)
+    return PendingMean(t, group, algorithm)
 
 
-def all_reduce_mean(t: Tensor, group=None) -> None:
-    """In-place mean of ``t`` over the ranks of ``group``: one RCCL all-reduce (``backend="nccl"``)."""
-    PendingMean(t, group).wait()
+def all_reduce_mean(t: Tensor, group=None, algorithm: str = "all_reduce") -> None:
+    """In-place mean of ``t`` over the ranks of ``group``: one RCCL all-reduce (``backend="nccl"``), or the direct
+    reduce-scatter + all-gather of ``direct_mean_``."""
+    PendingMean(t, group, algorithm).wait()
 
 
 def broadcast_tensors(tensors, src: int = 0, group=None) -> None:
@@ -148,10 +224,11 @@ class DistributedGenerator(nn.Module):
     all-reduces the gradients bucket by bucket while it runs.  Call ``broadcast_parameters()`` once after
     construction so that every rank starts from rank 0's weights."""
 
-    def __init__(self, module: nn.Module, bucket_mb: float = 16.0, group=None):
+    def __init__(self, module: nn.Module, bucket_mb: float = 16.0, group=None, algorithm: str = "all_reduce"):
         super().__init__()
         self.module = module
         self.group = group
+        self.algorithm = algorithm      # "all_reduce" | "direct" (see direct_mean_)
         m = module
         self.slices = phase_slices(m.in_channels, m.out_channels, m.num_features, m.num_blocks, m.growth_channels)
         # bucket_mb = float("inf"): one all-reduce of the whole buffer after the backward

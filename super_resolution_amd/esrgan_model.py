@@ -410,7 +410,8 @@ class _GeneratorFunction(torch.autograd.Function):
             packed_bwd = module.packed_bwd_parameters()
             reduce_in_buckets(flat, ctx.reducer.buckets,
                               lambda pb, pe: ops.generator_backward_range(gout, packed_bwd, ctx.saved, ws, flat, gin, cfg,
-                                                                          H, W, pb, pe), ctx.reducer.group)
+                                                                          H, W, pb, pe), ctx.reducer.group,
+                              getattr(ctx.reducer, "algorithm", "all_reduce"))
         params = module.conv_parameters()
         # one split for all 702 slices, then a reshape of the 4-d ones (biases are 1-d already)
         views = list(flat.split_with_sizes([p.numel() for p in params]))

@@ -34,8 +34,9 @@ class FlatAdam(torch.optim.Optimizer):
     ``nn.DataParallel(netD)`` at /root/reference/esrgan/train.py:108-111 with one process per GPU)."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 reduce_group=None):
+                 reduce_group=None, reduce_algorithm: str = "all_reduce"):
         self._reduce_group = reduce_group
+        self._reduce_algorithm = reduce_algorithm      # "all_reduce" | "direct" (ddp.direct_mean_)
         self._pending = None
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
@@ -155,7 +156,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._pending = []
         for fg in self._groups:
             grad = self._flat_grad(fg) if fg.flat is not None else None
-            self._pending.append((grad, start_all_reduce_mean(grad, self._reduce_group) if grad is not None else None))
+            self._pending.append((grad, start_all_reduce_mean(grad, self._reduce_group, self._reduce_algorithm)
+                                         if grad is not None else None))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -175,7 +177,7 @@ class FlatAdam(torch.optim.Optimizer):
                 grad = self._flat_grad(fg)
                 if grad is not None and self._reduce_group is not None:
                     from .ddp import all_reduce_mean
-                    all_reduce_mean(grad, self._reduce_group)
+                    all_reduce_mean(grad, self._reduce_group, self._reduce_algorithm)
             if grad is None:
                 continue
             self._check_views(fg, every=fg.step % 128 == 0)          # all of them now and then, the ends every step

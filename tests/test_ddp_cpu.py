@@ -125,3 +125,44 @@ def test_wrapped_generator_bucket_sizes_three_ranks(bucket_mb, n_buckets):
     mp.spawn(_worker_wrapped, args=(3, _free_port(), bucket_mb, ret), nprocs=3, join=True)
     assert ret["ok"] and ret["calls"] and ret["mean"]
     assert ret["buckets"] == n_buckets
+
+
+def _worker_direct(rank, world, port, ret):
+    """The direct reduce-scatter + all-gather (two all-to-all exchanges) against the plain mean: a length that does not
+    divide by the world size, the bucketed backward and the started-then-awaited form; every rank ends with the same bits."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 100_003
+    mine = torch.randn(n, generator=torch.Generator().manual_seed(200 + rank))
+    expect = sum(torch.randn(n, generator=torch.Generator().manual_seed(200 + r)) for r in range(world)) / world
+    a = mine.clone()
+    ddp.direct_mean_(a)
+    b = mine.clone()
+    pending = ddp.start_all_reduce_mean(b, algorithm="direct")
+    pending.wait()
+    # bucketed form over the generator's phase slices
+    sl = ddp.phase_slices(3, 3, 64, 2, 32)
+    buckets = ddp.plan_buckets(sl, 300_000)
+    flat = torch.full((sl[0][1],), float("nan"))
+    src = torch.randn(sl[0][1], generator=torch.Generator().manual_seed(300 + rank))
+
+    def run_phases(pb, pe):
+        for p in range(pb, pe):
+            lo, hi = sl[p]
+            flat[lo:hi] = src[lo:hi]
+
+    ddp.reduce_in_buckets(flat, buckets, run_phases, algorithm="direct")
+    want = sum(torch.randn(sl[0][1], generator=torch.Generator().manual_seed(300 + r)) for r in range(world)) / world
+    gathered = [torch.empty_like(a) for _ in range(world)]
+    dist.all_gather(gathered, a)
+    if rank == 0:
+        ret["mean"] = bool(torch.allclose(a, expect, rtol=1e-6, atol=1e-7)) and bool(torch.equal(a, b))
+        ret["same_bits"] = all(bool(torch.equal(g, a)) for g in gathered)
+        ret["buckets"] = len(buckets) >= 2 and bool(torch.allclose(flat, want, rtol=1e-6, atol=1e-7))
+    dist.destroy_process_group()
+
+
+def test_direct_reduce_scatter_all_gather_three_ranks():
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_direct, args=(3, _free_port(), ret), nprocs=3, join=True)
+    assert ret["mean"] and ret["same_bits"] and ret["buckets"]
