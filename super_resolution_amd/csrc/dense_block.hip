@@ -260,7 +260,7 @@ __device__ __forceinline__ void db_conv(f32x16 (&acc)[NB], const f32x16 (&pacc)[
             // steady state: one younger chunk in flight, two slots free after the barrier
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!DB_DEBUG(16)) __builtin_amdgcn_s_barrier();   // (bit 16, timing builds only: what the stage barriers cost)
         const unsigned char *pw;
         if constexpr (CO == 32) {
             pw = smem + DB_RING_OFF + c_slot * DB_CHUNK + (h * 9 * 32 + r) * 16;
