@@ -415,6 +415,43 @@ def generator_sr_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
     return torch.tanh(F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=3))
 
 
+# ---- CycleGAN HR -> LR generator (CycleGAN/CycleGAN_w_v1/CycleGAN.py:140-163; v2 is the same network) ----
+def generator_down_layout(in_channels: int = 3, out_channels: int = 3,
+                          base_channels: int = 64) -> List[Tuple[str, int, int, int]]:
+    """(state_dict prefix, cin, cout, kernel) of every conv in construction order (CycleGAN.py:143-156)."""
+    b = base_channels
+    return [("down.0", in_channels, b, 7), ("down.2", b, 2 * b, 4), ("down.4", 2 * b, 4 * b, 4),
+            ("res_blocks.0.conv1", 4 * b, 4 * b, 3), ("res_blocks.0.conv2", 4 * b, 4 * b, 3),
+            ("res_blocks.1.conv1", 4 * b, 4 * b, 3), ("res_blocks.1.conv2", 4 * b, 4 * b, 3),
+            ("out_conv", 4 * b, out_channels, 7)]
+
+
+def make_generator_down_state(seed: int, **cfg) -> StateDict:
+    """The weights ``torch.manual_seed(seed); GeneratorDown(**cfg)`` holds (default Conv2d initialisation)."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: StateDict = OrderedDict()
+    for name, cin, cout, k in generator_down_layout(**cfg):
+        fan_in = cin * k * k
+        w_bound = math.sqrt(3.0) * (math.sqrt(2.0 / (1 + 5.0)) / math.sqrt(fan_in))
+        sd[name + ".weight"] = torch.empty(cout, cin, k, k).uniform_(-w_bound, w_bound, generator=gen)
+        sd[name + ".bias"] = torch.empty(cout).uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=gen)
+    return sd
+
+
+def generator_down_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
+    """GeneratorDown.forward (CycleGAN.py:158-163): 7x7 conv + ReLU, two (4x4 / stride 2 conv, ReLU) stages, two
+    residual blocks, 7x7 conv, tanh."""
+    F = torch.nn.functional
+    h = F.relu(F.conv2d(x, sd["down.0.weight"], sd["down.0.bias"], padding=3))
+    h = F.relu(F.conv2d(h, sd["down.2.weight"], sd["down.2.bias"], stride=2, padding=1))
+    h = F.relu(F.conv2d(h, sd["down.4.weight"], sd["down.4.bias"], stride=2, padding=1))
+    for i in range(2):
+        p = f"res_blocks.{i}."
+        t = F.relu(F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
+        h = h + F.conv2d(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    return torch.tanh(F.conv2d(h, sd["out_conv.weight"], sd["out_conv.bias"], padding=3))
+
+
 # ---- conditional VAE ("condtional VAE/model.py":53-215) ----
 def _bn(sd: StateDict, name: str, x: torch.Tensor, training: bool) -> torch.Tensor:
     """nn.BatchNorm2d as the reference applies it (default eps / momentum); in training mode the running

@@ -1,7 +1,7 @@
 """The CycleGAN super-resolution generator on the MI355X conv core.
 
-Drop-in for ``ResidualBlock`` / ``GeneratorSR`` of /root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-137 (the
-v2 script, CycleGAN_w_v2/CycleGAN2.py:102-150, defines the same network): same constructor arguments, same
+Drop-in for ``ResidualBlock`` / ``GeneratorSR`` / ``GeneratorDown`` of /root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-163
+(the v2 script, CycleGAN_w_v2/CycleGAN2.py:102-176, defines the same networks): same constructor arguments, same
 ``state_dict`` keys (``conv1.0.*``, ``res_blocks.N.conv{1,2}.*``, ``up{1,2}.0.*``, ``conv_out.*``), NCHW fp32 in and
 out, trainable through autograd.  Every 3x3 convolution — the residual blocks and the two sub-pixel stages, 97 % of
 the FLOPs — runs on the HIP kernels of ``conv_core`` (bf16 operands, fp32 accumulation) with ReLU fused as a
@@ -82,3 +82,29 @@ class GeneratorSR(nn.Module):
             # kernel on the blocked layout
             xb = cc.pixel_shuffle2(cc.conv3x3(xb, conv.weight, conv.bias, 0.0))
         return self.tanh(self.conv_out(cc.from_blocked(xb, self.conv_out.in_channels)))
+
+
+class GeneratorDown(nn.Module):
+    """CycleGAN.py:140-163 — HR -> LR (/4): 7x7 conv + ReLU, two (4x4 / stride 2 conv, ReLU) stages, two residual blocks
+    at four times the base width, 7x7 conv, tanh.  The residual blocks' 3x3 convs run on the conv core (as in
+    ``GeneratorSR``); the 7x7 and 4x4 convs stay on stock PyTorch-ROCm."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, base_channels: int = 64):
+        super().__init__()
+        if (4 * base_channels) % 16:
+            raise ValueError("4 * base_channels must be a multiple of 16 (the fp32 trunk output runs on 16-channel groups)")
+        b = base_channels
+        self.down = nn.Sequential(nn.Conv2d(in_channels, b, kernel_size=7, stride=1, padding=3), nn.ReLU(inplace=True),
+                                  nn.Conv2d(b, b * 2, kernel_size=4, stride=2, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(b * 2, b * 4, kernel_size=4, stride=2, padding=1), nn.ReLU(inplace=True))
+        self.res_blocks = nn.Sequential(ResidualBlock(b * 4), ResidualBlock(b * 4))
+        self.out_conv = nn.Conv2d(b * 4, out_channels, kernel_size=7, stride=1, padding=3)
+        self.tanh = nn.Tanh()
+
+    def forward(self, x: Tensor) -> Tensor:
+        _need_cuda(x, "GeneratorDown")
+        v = self.down(x.float())                                    # 7x7 and 4x4 / stride 2: stock PyTorch-ROCm
+        xb, trunk = cc.to_blocked(v), _nchw_to_f32(v)
+        for block in self.res_blocks:
+            xb, trunk = block._run(xb, trunk)
+        return self.tanh(self.out_conv(cc.f32_as_nchw(trunk)))

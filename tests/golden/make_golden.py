@@ -10,6 +10,7 @@ text is stored: fixtures hold seeds, inputs, outputs and gradients only.
     cd /tmp && python /root/repo/tests/golden/make_golden.py g8     # only g8_adversarial_step.npz
     cd /tmp && python /root/repo/tests/golden/make_golden.py g9     # only g9_cyclegan_sr.npz (+ manifest)
     cd /tmp && python /root/repo/tests/golden/make_golden.py g10    # only g10_cvae.npz (+ manifest)
+    cd /tmp && python /root/repo/tests/golden/make_golden.py g11    # only g11_cyclegan_down.npz (+ manifest)
 """
 import importlib.util
 import os
@@ -134,6 +135,31 @@ def make_g9():
             f.write(f"{k} {tuple(v.shape)}\n")
 
 
+def make_g11():
+    # G11: the CycleGAN HR -> LR generator (CycleGAN/CycleGAN_w_v1/CycleGAN.py:140-163), loaded like G9's class.
+    for m in ("torchvision", "torchvision.transforms"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    spec = importlib.util.spec_from_file_location("ref_cyclegan_v1", "/root/reference/CycleGAN/CycleGAN_w_v1/CycleGAN.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(11)
+    net = mod.GeneratorDown(base_channels=16)
+    g = torch.Generator().manual_seed(111)
+    x = (torch.rand(2, 3, 24, 20, generator=g) * 2 - 1).requires_grad_(True)
+    r = torch.randn(2, 3, 6, 5, generator=g)
+    out = net(x)
+    (out * r).sum().backward()
+    st = {"seed": 11, "base_channels": 16, "x": x.detach().numpy(), "r": r.numpy(), "out": out.detach().numpy(),
+          "grad_x": x.grad.numpy()}
+    put_grads(st, net, full=("down.0.bias", "res_blocks.1.conv2.bias", "res_blocks.0.conv1.weight", "out_conv.bias"))
+    weight_sums(st, net)
+    np.savez_compressed(os.path.join(HERE, "g11_cyclegan_down.npz"), **st)
+    with open(os.path.join(HERE, "g11_cyclegan_down_manifest.txt"), "w") as f:
+        for k, v in mod.GeneratorDown().state_dict().items():
+            f.write(f"{k} {tuple(v.shape)}\n")
+
+
 def make_g10():
     # G10: the conditional VAE ("condtional VAE/model.py":53-215).  The file imports torchvision.models at top level
     # (for its VGG loss class, which needs ImageNet weights and is not built): an empty stand-in module lets it load.
@@ -179,6 +205,10 @@ def main():
     if sys.argv[1:] == ["g9"]:
         torch.set_num_threads(8)
         make_g9()
+        return
+    if sys.argv[1:] == ["g11"]:
+        torch.set_num_threads(8)
+        make_g11()
         return
     ref = load_reference()
     torch.set_num_threads(8)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import esrgan_oracle as O
-from super_resolution_amd.cyclegan import GeneratorSR, ResidualBlock
+from super_resolution_amd.cyclegan import GeneratorDown, GeneratorSR, ResidualBlock
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -126,3 +126,35 @@ def test_residual_conv_with_the_skip_in_its_epilogue():
     assert rel_l2(trunk_nchw.grad.cpu(), tr.grad) < 1e-6
     assert rel_l2(x.grad.cpu(), xr.grad) < 1e-2          # the conv's incoming gradient is stored in bf16
     assert rel_l2(w.grad.cpu(), wr.grad) < 1e-2 and rel_l2(b.grad.cpu(), br.grad) < 1e-2
+
+
+def test_generator_down_against_reference_vector(golden):
+    """The HR -> LR generator (CycleGAN.py:140-163) against the vector made from the reference class: output, input
+    gradient and parameter gradients (the two residual blocks run on the conv core in bf16)."""
+    g = golden("g11_cyclegan_down.npz")
+    b = int(g["base_channels"])
+    sd = O.make_generator_down_state(int(g["seed"]), base_channels=b)
+    net = GeneratorDown(base_channels=b)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    out = net(x)
+    ref = torch.from_numpy(g["out"])
+    assert out.shape == ref.shape
+    p = psnr2(out.detach().cpu(), ref)
+    print(f"GeneratorDown bf16 vs reference fp32: PSNR {p:.1f} dB (peak 2)")
+    assert p >= 50.0
+    (out * torch.from_numpy(g["r"]).to(DEV)).sum().backward()
+    assert rel_l2(x.grad.cpu(), torch.from_numpy(g["grad_x"])) < 0.1
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        got, want = prm.grad.double().abs().sum().item(), float(g[f"gabs/{name}"])
+        worst = max(worst, abs(got - want) / want)
+        if f"gfull/{name}" in g:
+            assert rel_l2(prm.grad.cpu(), torch.from_numpy(g[f"gfull/{name}"])) < 0.1, name
+    assert worst < 0.05, worst
+    # default width on a ragged image
+    big = GeneratorDown().to(DEV).eval()
+    with torch.no_grad():
+        y = big(torch.rand(1, 3, 36, 52, device=DEV) * 2 - 1)
+    assert y.shape == (1, 3, 9, 13) and bool(torch.isfinite(y).all())

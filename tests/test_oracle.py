@@ -233,3 +233,18 @@ def test_conditional_vae_g10(golden):
     keys = [ln.split(" ", 1)[0] for ln in open(os.path.join(os.path.dirname(__file__), "golden",
                                                            "g10_cvae_manifest.txt")).read().splitlines()]
     assert keys == list(O.make_cvae_state(0).keys())
+
+
+def test_generator_down_oracle_matches_reference_vector(golden):
+    """G11: the oracle's restatement of CycleGAN.py:140-163 against the output of the reference class, its weights from
+    the same seed (checked through the stored weight sums) and the key schema of the default network."""
+    g = golden("g11_cyclegan_down.npz")
+    sd = O.make_generator_down_state(int(g["seed"]), base_channels=int(g["base_channels"]))
+    for k, v in sd.items():
+        assert abs(v.double().sum().item() - float(g[f"wsum/{k}"])) < 1e-9 * max(1.0, abs(float(g[f"wsum/{k}"]))) + 1e-6, k
+    out = O.generator_down_forward(sd, torch.from_numpy(g["x"]))
+    assert (out - torch.from_numpy(g["out"])).abs().max().item() < 1e-6
+    import os
+    manifest = open(os.path.join(os.path.dirname(__file__), "golden", "g11_cyclegan_down_manifest.txt")).read().split("\n")
+    keys = [ln.split(" ")[0] for ln in manifest if ln]
+    assert keys == list(O.make_generator_down_state(0).keys())
