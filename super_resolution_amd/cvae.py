@@ -10,7 +10,7 @@ on the HIP kernels of ``conv_core`` (bf16 operands, fp32 accumulation; fp32 conv
 transposed convolutions, the linear layers, the decoder's BatchNorms, PixelShuffle, bicubic interpolation and tanh stay
 on stock PyTorch-ROCm.  ``condition_processor`` keeps its
 parameters (checkpoints carry them) but is not evaluated: the reference computes its output and never uses it
-(model.py:175).  ``VGGPerceptualLoss`` of the same file needs torchvision's ImageNet weights and is not provided.
+(model.py:175).  ``VGGPerceptualLoss`` of the same file is below: its convs, pools and L1 reductions on the conv core too.
 """
 import torch
 from torch import Tensor, nn
@@ -105,3 +105,66 @@ class CVAE(nn.Module):
         dummy = (torch.zeros(b, 64, 32, 32, device=dev), torch.zeros(b, 128, 16, 16, device=dev),
                  torch.zeros(b, 256, 8, 8, device=dev), torch.zeros(b, 512, 4, 4, device=dev))
         return self.decode(z, condition, dummy)
+
+
+class VGGPerceptualLoss(nn.Module):
+    """``VGGPerceptualLoss`` of /root/reference/condtional VAE/model.py:8-50: the sum over four VGG19 stages (relu1_2,
+    relu2_2, relu3_4, relu4_4 = ``features[:4]``, ``[4:9]``, ``[9:18]``, ``[18:27]``) of the mean L1 distance between
+    the features of two images given in [-1, 1].  Same ``state_dict`` keys (``blocks.K.N.weight`` with torchvision's
+    layer numbers, buffers ``mean`` / ``std``), parameters frozen.  The twelve 3x3 convs (ReLU fused), the three max
+    pools and the four L1 reductions run on the HIP kernels of ``conv_core``; the gradient flows to the first argument
+    (and to the second where it requires one), as in the reference.
+
+    The ImageNet weights come from torchvision as in the reference (:11); where torchvision is not installed pass
+    ``pretrained=False`` and load a ``state_dict`` with the reference's keys."""
+
+    def __init__(self, *, pretrained: bool = True):
+        super().__init__()
+        from .esrgan_aux import _vgg19_feature_layers
+        layers = _vgg19_feature_layers()[:27]
+        if pretrained:
+            try:
+                from torchvision import models
+            except ImportError as exc:
+                raise ImportError("VGGPerceptualLoss(pretrained=True) takes the ImageNet weights from torchvision, which "
+                                  "is not installed; use pretrained=False and load_state_dict") from exc
+            for dst, src in zip(layers, models.vgg19(pretrained=True).features):
+                if isinstance(dst, nn.Conv2d):
+                    dst.load_state_dict(src.state_dict())
+        features = nn.Sequential(*layers)
+        self.blocks = nn.ModuleList([features[:4], features[4:9], features[9:18], features[18:27]])   # (keys keep the
+        for p in self.parameters():                                                                # original numbers)
+            p.requires_grad = False
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def normalize(self, x: Tensor) -> Tensor:
+        return (x - self.mean) / self.std
+
+    @staticmethod
+    def _run_block(block: nn.Sequential, h: Tensor) -> Tensor:
+        mods = list(block)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
+            if isinstance(m, nn.Conv2d):
+                relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+                h = cc.conv3x3(h, m.weight, m.bias, 0.0 if relu else 1.0)     # ReLU = LeakyReLU of slope 0, fused
+                i += int(relu)
+            elif isinstance(m, nn.MaxPool2d):
+                h = cc.max_pool2x2(h)
+            else:
+                h = torch.relu(h)
+        return h
+
+    def forward(self, x: Tensor, y: Tensor) -> Tensor:
+        _need_cuda(x)
+        xb = cc.to_blocked(self.normalize((x.float() + 1) / 2).contiguous())
+        yb = cc.to_blocked(self.normalize((y.float() + 1) / 2).contiguous())
+        loss = 0.0
+        for block in self.blocks:
+            xb, yb = self._run_block(block, xb), self._run_block(block, yb)
+            # (VGG19's widths are whole units: the mean over the blocked tensor is the mean over the NCHW one)
+            loss = loss + cc.l1_loss(xb, yb)
+        return loss

@@ -97,3 +97,47 @@ def test_cvae_forward_backward_and_sample():
     with torch.no_grad():
         s = net.sample(2, x[:2].to(DEV))
     assert s.shape == (2, 3, 128, 128) and torch.isfinite(s).all()
+
+
+def test_vgg_perceptual_loss_on_the_conv_core():
+    """VGGPerceptualLoss (model.py:8-50) with seeded weights against the same arithmetic in torch on bf16-rounded conv
+    operands (the ImageNet weights need torchvision: parity with those is unpinned, the arithmetic is not), its key
+    schema, and the gradient reaching the first argument."""
+    from super_resolution_amd.cvae import VGGPerceptualLoss
+    import torch.nn.functional as F
+    torch.manual_seed(31)
+    net = VGGPerceptualLoss(pretrained=False)
+    keys = list(net.state_dict().keys())
+    assert keys[:4] == ["mean", "std", "blocks.0.0.weight", "blocks.0.0.bias"] and "blocks.1.5.weight" in keys
+    assert "blocks.2.16.weight" in keys and "blocks.3.25.bias" in keys and len(keys) == 2 + 2 * 12
+    assert not any(p.requires_grad for p in net.parameters())
+    net = net.to(DEV)
+    gen = torch.Generator().manual_seed(32)
+    x0 = torch.rand(2, 3, 32, 48, generator=gen) * 2 - 1
+    y0 = torch.rand(2, 3, 32, 48, generator=gen) * 2 - 1
+    x = x0.to(DEV).requires_grad_(True)
+    loss = net(x, y0.to(DEV))
+    loss.backward()
+
+    def bf(t):
+        return t.to(torch.bfloat16).float()
+
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    xr = x0.clone().requires_grad_(True)
+
+    def feats(img):
+        h = bf((((img + 1) / 2) - sd["mean"]) / sd["std"])
+        out = []
+        for bi, idx in enumerate(([0, 2], [5, 7], [10, 12, 14, 16], [19, 21, 23, 25])):
+            if bi:
+                h = F.max_pool2d(h, 2)
+            for n in idx:
+                h = bf(F.relu(F.conv2d(h, bf(sd[f"blocks.{bi}.{n}.weight"]), sd[f"blocks.{bi}.{n}.bias"], padding=1)))
+            out.append(h)
+        return out
+
+    ref = sum(F.l1_loss(a, b) for a, b in zip(feats(xr), feats(y0)))
+    ref.backward()
+    print("perceptual loss", loss.item(), "reference arithmetic", ref.item())
+    assert abs(loss.item() - ref.item()) < 5e-3 * abs(ref.item())
+    assert rel_l2(x.grad.cpu(), xr.grad) < 0.1
