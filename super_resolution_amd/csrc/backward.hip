@@ -167,6 +167,11 @@ struct WgradArgs {
     long long z_slab_off[WGRAD_MAX_JOBS], z_bias_off[WGRAD_MAX_JOBS];   // in floats from `slabs`; bias < 0: none
 };
 
+#ifdef SR355_EXP_WG_NOLOAD   /* timing experiment (wrong results): every tile load out of range, no memory traffic */
+#define SR355_EXP_WG_NOLOAD_V true
+#else
+#define SR355_EXP_WG_NOLOAD_V false
+#endif
 namespace {
 constexpr int WTH = 4;                     // tile rows
 constexpr int WPX = WTH * 32;              // 128 output pixels
@@ -249,6 +254,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
             const int j = k * 3 + wave;                                                                 \
             voff[k] = W_OOB;                                                                            \
+            if (SR355_EXP_WG_NOLOAD_V) continue;                                                        \
             if (j < G::DY_I) {                                                                          \
                 const int i = j * 64 + lane; /* [u][py][px] */                                          \
                 const int u = i / WPX;                                                                  \
