@@ -712,11 +712,15 @@ int sr355_generator_num_convs(const sr355_generator_cfg *cfg) {
     return 1 + 15 * cfg->num_blocks + 5;
 }
 
+// The packed blob ends with room for the table of pack jobs (one per conv), which sr355_generator_pack copies there so
+// that one launch packs every conv; the forward passes read [0, total) only.
+static size_t pack_table_bytes(size_t n_convs) { return align256(n_convs * sizeof(PackJob)); }
+
 size_t sr355_generator_packed_bytes(const sr355_generator_cfg *cfg) {
     if (!cfg_ok(cfg)) return 0;
     size_t total = 0;
-    conv_specs(*cfg, &total);
-    return total;
+    const size_t n = conv_specs(*cfg, &total).size();
+    return total + pack_table_bytes(n);
 }
 
 int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_ptrs, const float *const *b_ptrs,
@@ -725,9 +729,9 @@ int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_p
     size_t total = 0;
     std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
     if (!w_ptrs || !b_ptrs || n_convs != (int)specs.size() || !packed || !aligned16(packed) ||
-        packed_bytes < total) {
-        set_error("generator_pack: need %zu conv tensors and %zu bytes (got %d, %zu)", specs.size(), total,
-                  n_convs, packed_bytes);
+        packed_bytes < total + pack_table_bytes(specs.size())) {
+        set_error("generator_pack: need %zu conv tensors and %zu bytes (got %d, %zu)", specs.size(),
+                  total + pack_table_bytes(specs.size()), n_convs, packed_bytes);
         return SR355_ERR_INVALID;
     }
     unsigned char *base = (unsigned char *)packed;
@@ -740,7 +744,7 @@ int sr355_generator_pack(const sr355_generator_cfg *cfg, const float *const *w_p
         jobs[i] = PackJob{w_ptrs[i], b_ptrs[i], base + specs[i].w_off, (float *)(base + specs[i].b_off), specs[i].cout,
                           specs[i].cin, specs[i].split, specs[i].f16};
     }
-    return launch_pack_weight_batch(jobs.data(), (int)jobs.size(), cfg->dtype, (hipStream_t)stream);
+    return launch_pack_weight_table(jobs.data(), (int)jobs.size(), cfg->dtype, base + total, (hipStream_t)stream);
 }
 
 size_t sr355_generator_workspace_bytes(const sr355_generator_cfg *cfg, int N, int H, int W) {
@@ -1242,7 +1246,7 @@ int sr355_generator_forward(const sr355_generator_cfg *cfg, const void *packed, 
     if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
     size_t total = 0;
     std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
-    int rc = forward_checks("generator_forward", cfg, packed, packed_bytes, total, in_nchw, out_nchw, N, H, W);
+    int rc = forward_checks("generator_forward", cfg, packed, packed_bytes, total + pack_table_bytes(specs.size()), in_nchw, out_nchw, N, H, W);
     if (rc) return rc;
     const Workspace ws = carve(*cfg, N, H, W);
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) || workspace_bytes < ws.total) {
@@ -1270,7 +1274,7 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
     if (!cfg_ok(cfg)) return SR355_ERR_INVALID;
     size_t total = 0;
     std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
-    int rc = forward_checks("generator_forward_u8", cfg, packed, packed_bytes, total,
+    int rc = forward_checks("generator_forward_u8", cfg, packed, packed_bytes, total + pack_table_bytes(specs.size()),
                             reinterpret_cast<const float *>(in_u8hwc), reinterpret_cast<float *>(out_u8hwc), N, H, W);
     if (rc) return rc;
     const Workspace ws = carve(*cfg, N, H, W);
@@ -1382,7 +1386,7 @@ int sr355_generator_forward_train(const sr355_generator_cfg *cfg, const void *pa
     if (!train_ok(cfg)) return SR355_ERR_INVALID;
     size_t total = 0;
     std::vector<ConvSpec> specs = conv_specs(*cfg, &total);
-    int rc = forward_checks("generator_forward_train", cfg, packed, packed_bytes, total, in_nchw, out_nchw, N, H, W);
+    int rc = forward_checks("generator_forward_train", cfg, packed, packed_bytes, total + pack_table_bytes(specs.size()), in_nchw, out_nchw, N, H, W);
     if (rc) return rc;
     const Workspace ws = carve(*cfg, N, H, W);
     const Saved sv = carve_saved(*cfg, ws, N, H, W);
@@ -1411,7 +1415,7 @@ int sr355_generator_forward_train(const sr355_generator_cfg *cfg, const void *pa
 // data-gradient convs use one shared all-zero bias at the start of the blob).
 struct BwdPack {
     std::vector<size_t> rdb;   // [3*nb][5]: index (i*5 + j)
-    size_t trunk, up1, up2, hr, last, first, zero_bias, total;
+    size_t trunk, up1, up2, hr, last, first, zero_bias, table, total;
 };
 
 static BwdPack carve_bwd(const sr355_generator_cfg &c) {
@@ -1434,6 +1438,7 @@ static BwdPack carve_bwd(const sr355_generator_cfg &c) {
     p.trunk = take(sq), p.up1 = take(sq), p.up2 = take(sq), p.hr = take(sq);
     p.last = take((size_t)cin_units_for(c.out_channels, c.dtype) * 9 * cout_pad_for(nf) * 16);
     p.first = take((size_t)(nf / 8) * 9 * cout_pad_for(c.in_channels) * 16);
+    p.table = take(((size_t)45 * c.num_blocks + 6) * sizeof(PackTJob));   // the pack jobs themselves (one launch packs all)
     p.total = off;
     return p;
 }
@@ -1498,7 +1503,11 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
     if ((rc = launch_pack_weight_t(w_ptrs[0], nf, cfg->in_channels, 0, cfg->in_channels, dt, 1.f, base + bp.first, 0,
                                    cout_pad_for(cfg->in_channels), stream)))
         return rc;
-    return launch_pack_weight_t_batch(jobs.data(), (int)jobs.size(), dt, stream);
+    if (jobs.size() > (size_t)45 * nb + 6) {
+        set_error("generator_pack_bwd: job table overflow");
+        return SR355_ERR_INVALID;
+    }
+    return launch_pack_weight_t_table(jobs.data(), (int)jobs.size(), dt, base + bp.table, stream);
 }
 
 // Backward workspace.

@@ -84,6 +84,13 @@ __global__ void pack_weight_t_batch_kernel(const PackTJobTable t) {
     pack_weight_t_body<T>(j.w, (T *)j.wp, j.Co, j.Ci, j.ci_lo, j.n_out, j.unit_off, j.cout_pad, j.scale);
 }
 
+// the jobs in device memory: any number of them in one launch (blockIdx.y = job)
+template <typename T>
+__global__ void pack_weight_t_table_kernel(const PackTJob *__restrict__ jobs) {
+    const PackTJob j = jobs[blockIdx.y];
+    pack_weight_t_body<T>(j.w, (T *)j.wp, j.Co, j.Ci, j.ci_lo, j.n_out, j.unit_off, j.cout_pad, j.scale);
+}
+
 // ------------------------------------------------------------------------------------------
 // out[n][y][c][x] = sum of the 2x2 block of in at (2y.., 2x..), optionally gated by the sign of a
 // forward activation; written as fp32 trunk and/or as blocked activations at a unit offset.
@@ -518,6 +525,22 @@ int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream
         if (check_hip(hipGetLastError(), "pack_weight_t batch launch")) return SR355_ERR_HIP;
     }
     return SR355_OK;
+}
+
+int launch_pack_weight_t_table(const PackTJob *jobs_host, int n, int dtype, void *table_dev, hipStream_t stream) {
+    if (n < 1) return SR355_OK;
+    if (n > 65535) {
+        set_error("pack_weight_t table: %d jobs exceed one launch", n);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    if (check_hip(hipMemcpyAsync(table_dev, jobs_host, (size_t)n * sizeof(PackTJob), hipMemcpyHostToDevice, stream),
+                  "hipMemcpyAsync"))
+        return SR355_ERR_HIP;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_t_table_kernel<__bf16>, dim3(32, n), dim3(256), 0, stream, (const PackTJob *)table_dev);
+    else
+        hipLaunchKernelGGL(pack_weight_t_table_kernel<float>, dim3(32, n), dim3(256), 0, stream, (const PackTJob *)table_dev);
+    return check_hip(hipGetLastError(), "pack_weight_t table launch");
 }
 
 int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const void *mask, int mask_units,

@@ -142,9 +142,44 @@ __global__ void pack_weight_batch_kernel(const PackJobTable t) {
     pack_weight_body<T>(j.w, j.bias, (T *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, split);
 }
 
+// The same with the jobs in device memory (any number of them in ONE launch; blockIdx.y = job): a training step
+// repacks every conv after the optimizer update, and 64 jobs per launch in the kernel arguments made that 6 launches.
+template <typename T>
+__global__ void pack_weight_table_kernel(const PackJob *__restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    constexpr int CPU = 16 / sizeof(T);
+    const int split = sizeof(T) == 2 ? j.split : 0;
+    const int real = split == SR355_SPLIT_INPUT ? 2 * j.cin : j.cin;
+    const int U = ((real + CPU - 1) / CPU + 1) / 2 * 2;
+    if constexpr (sizeof(T) == 2) {
+        if (j.f16) {
+            pack_weight_body<_Float16>(j.w, j.bias, (_Float16 *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, 0);
+            return;
+        }
+    }
+    pack_weight_body<T>(j.w, j.bias, (T *)j.wp, j.bp, j.cout, j.cin, U, (j.cout + 31) / 32 * 32, split);
+}
+
 static unsigned grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_pack_weight_table(const PackJob *jobs_host, int n, int dtype, void *table_dev, hipStream_t stream) {
+    if (n < 1) return SR355_OK;
+    if (n > 65535) {
+        set_error("pack_weight table: %d jobs exceed one launch", n);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    // (a pageable source: the runtime has staged it when the call returns, so the caller's vector may go)
+    if (check_hip(hipMemcpyAsync(table_dev, jobs_host, (size_t)n * sizeof(PackJob), hipMemcpyHostToDevice, stream),
+                  "hipMemcpyAsync"))
+        return SR355_ERR_HIP;
+    if (dtype == SR355_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_weight_table_kernel<__bf16>, dim3(48, n), dim3(256), 0, stream, (const PackJob *)table_dev);
+    else
+        hipLaunchKernelGGL(pack_weight_table_kernel<float>, dim3(48, n), dim3(256), 0, stream, (const PackJob *)table_dev);
+    return check_hip(hipGetLastError(), "pack_weight table launch");
 }
 
 int launch_nchw_to_blocked(const float *src, int N, int C, int H, int W, int dtype, void *dst,

@@ -171,6 +171,9 @@ struct PackTJob {     // one launch_pack_weight_t call
     float scale;
 };
 int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t stream);
+// All jobs in one launch each: the table is copied to `table_dev` (n * sizeof(job) bytes of device memory) first.
+int launch_pack_weight_table(const PackJob *jobs_host, int n, int dtype, void *table_dev, hipStream_t stream);
+int launch_pack_weight_t_table(const PackTJob *jobs_host, int n, int dtype, void *table_dev, hipStream_t stream);
 int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream_t stream);
 
 // ---- backward.hip ----
