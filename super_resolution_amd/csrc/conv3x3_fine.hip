@@ -330,7 +330,14 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int ty_i = tr % a.tiles_y;
             const int n = tr / a.tiles_y;
             const int x = tx_i * 32 + r;
-            if (conv_epilogue_tile_ok(a)) {
+            if (conv_epilogue_plain_ok(a)) {
+                if (a.f16_out)
+                    conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
+                                                           cb * G::CO, h, !SR355_DBG(a, 2));
+                else
+                    conv_epilogue_tile_plain<MB, NB, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
+                                                            cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if (conv_epilogue_tile_ok(a)) {
                 conv_epilogue_tile<MB, NB>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x, cb * G::CO, h,
                                            !SR355_DBG(a, 2));
             } else {

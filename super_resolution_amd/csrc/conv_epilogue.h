@@ -117,6 +117,64 @@ __device__ __forceinline__ bool conv_epilogue_tile_ok(const ConvArgs &a) {
     return !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0;
 }
 
+// The commonest shape of all — bias, LeakyReLU, one blocked 16-bit output, nothing else (every growth conv, the
+// up-sampling convs, most of the discriminator and the VGG stack) — without the per-quad tests of the general form
+// below: a fifth of its instructions, which matters where a tile has few stages (64 input channels: the epilogue of
+// the general form is as long as half the tile's MFMA stream).  Same arithmetic as the general form: for a slope in
+// [0, 1], max(v, slope * v) is v > 0 ? v : slope * v.
+__device__ __forceinline__ bool conv_epilogue_plain_ok(const ConvArgs &a) {
+    return conv_epilogue_tile_ok(a) && a.out_act && !a.out_f32 && !a.mask_act && !a.res_act && !a.res1 && !a.res2 &&
+           a.slope >= 0.f && a.slope <= 1.f;
+}
+
+template <int MB, int NB, bool F16OUT>
+__device__ __forceinline__ void conv_epilogue_tile_plain(const ConvArgs &a, epi_f32x16 (&acc)[MB][NB],
+                                                         const unsigned char *bias_lds, int n, int y0, int x, int cb_co,
+                                                         int h, bool live) {
+    constexpr int OOB = 0x7fffff00;
+    const int H = a.H, W = a.W;
+    const int wstep = __builtin_amdgcn_readfirstlane(W * 16);          // bytes from one unit of a row to the next
+    const size_t img_bytes = (size_t)H * W * a.out_units * 16;
+    const unsigned long long p = (unsigned long long)a.out_act + (size_t)n * img_bytes;
+    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p)),
+        0, __builtin_amdgcn_readfirstlane((int)img_bytes), 0x00020000);
+    const float slope = a.slope;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + (mb * 32 + q * 8 + h * 4) * 4);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int y = y0 + nb;
+                const bool ok = live && x < W && y < H;
+                const int vo_act = ok ? ((y * a.out_units + a.out_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+                float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
+                              acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], v[j] * slope);
+                epi_v2u o;
+                if constexpr (F16OUT) {
+                    epi_f16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
+                    o = __builtin_bit_cast(epi_v2u, pk);
+                } else {
+                    epi_bf16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[j];
+                    o = __builtin_bit_cast(epi_v2u, pk);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_act, vo_act, (mb * 4 + q) * wstep, 0);
+            }
+        }
+    }
+}
+
 // AUX is the cache-policy operand of the stores: 0 = plain, 16 = write-through (sc1), which is what a kernel whose
 // workgroups read each other's output inside one launch needs.
 template <int MB, int NB, int AUX = 0>
