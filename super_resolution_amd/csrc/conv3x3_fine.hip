@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
                 else
                     conv_epilogue_tile_plain<MB, NB, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
                                                             cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if (MB == 1 && cb == 0 && conv_epilogue_rgb_ok(a)) {
+                if constexpr (MB == 1)
+                    conv_epilogue_rgb<NB>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x, h, !SR355_DBG(a, 2));
             } else if (conv_epilogue_tile_ok(a)) {
                 conv_epilogue_tile<MB, NB>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x, cb * G::CO, h,
                                            !SR355_DBG(a, 2));

@@ -175,6 +175,45 @@ __device__ __forceinline__ void conv_epilogue_tile_plain(const ConvArgs &a, epi_
     }
 }
 
+// The last conv of a generator (at most 4 output channels padded to a block of 32, fp32 NCHW or uint8 HWC output,
+// no residuals): only the first quad of the lanes h = 0 holds real channels.  Same arithmetic as conv_epilogue_quad.
+__device__ __forceinline__ bool conv_epilogue_rgb_ok(const ConvArgs &a) {
+    return a.cout_real <= 4 && (a.out_nchw || a.out_u8) && !a.out_act && !a.out_f32 && !a.mask_act && !a.res_act &&
+           !a.res1 && !a.res2;
+}
+
+template <int NB>
+__device__ __forceinline__ void conv_epilogue_rgb(const ConvArgs &a, epi_f32x16 (&acc)[1][NB], const unsigned char *bias_lds,
+                                                  int n, int y0, int x, int h, bool live) {
+    const int H = a.H, W = a.W, C = a.cout_real;
+    const float slope = a.slope;
+    const float4 bv = *reinterpret_cast<const float4 *>(bias_lds);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int y = y0 + nb;
+        float v[4] = {acc[0][nb][0] + bv.x, acc[0][nb][1] + bv.y, acc[0][nb][2] + bv.z, acc[0][nb][3] + bv.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][nb][e] = 0.f;
+        if (!(live && h == 0 && x < W && y < H)) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+        const size_t row = (size_t)n * H + y;
+        if (a.out_nchw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < C) a.out_nchw[(((size_t)n * C + j) * H + y) * W + x] = v[j];
+        }
+        if (a.out_u8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < C) {
+                    const float cl = v[j] < 0.f ? 0.f : (v[j] > 1.f ? 1.f : v[j]);
+                    a.out_u8[((row * W) + x) * C + j] = (unsigned char)(int)(cl * 255.0f);
+                }
+        }
+    }
+}
+
 // AUX is the cache-policy operand of the stores: 0 = plain, 16 = write-through (sc1), which is what a kernel whose
 // workgroups read each other's output inside one launch needs.
 template <int MB, int NB, int AUX = 0>
