@@ -245,41 +245,76 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     const int dy_img_bytes = ((H + a.dy_s2) >> a.dy_s2) * a.dy_units * Wd * 16;
     const int n_tiles = a.N * a.tiles_y * a.tiles_x;
 
-    int voff[G::KMAX];
+    // Source offsets of this wave's DMA instructions (item j = k * 3 + wave of a tile: a 16-byte piece of the output
+    // gradient [u][py][px] or of the haloed input [u][ty][tx]).  What does not depend on the tile is computed once:
+    // the item's position relative to the tile origin (ry, rx; an item that never exists gets a row no image has)
+    // and the part of its offset that position contributes (cst).  Per tile there remain one add and two unsigned
+    // compares per item, and the tile coordinates advance by the launch's stride without a division (a tile is
+    // 24 MFMAs a wave: a set-up of a few hundred instructions per tile would be longer than the tile itself).
+    int voff[G::KMAX], ry[G::KMAX], rx[G::KMAX], cst[G::KMAX];
+#pragma unroll
+    for (int k = 0; k < G::KMAX; ++k) {
+        const int j = k * 3 + wave;
+        ry[k] = 0x40000000, rx[k] = 0, cst[k] = 0;
+        if (j < G::DY_I) {
+            const int i = j * 64 + lane; /* [u][py][px] */
+            const int u = i / WPX;
+            const int pp = i - u * WPX;
+            const int py = pp >> 5, px = pp & 31;
+            if (!(a.dy_s2 && ((py | px) & 1))) ry[k] = py;
+            rx[k] = px;
+            cst[k] = (((py >> a.dy_s2) * a.dy_units + a.dy_unit_off + u) * Wd + (px >> a.dy_s2)) * 16;
+        } else if (j < G::JTOT) {
+            const int i = (j - G::DY_I) * 64 + lane; /* [u][ty][tx] haloed */
+            const int u = i / WIPX;
+            const int pp = i - u * WIPX;
+            const int ty = pp / 34;
+            const int tx = pp - ty * 34;
+            const int uu = chunk * 4 + u;
+            if (i < G::IN_ITEMS && uu < a.in_units) ry[k] = ty - 1;
+            rx[k] = tx - 1;
+            cst[k] = ((((ty - 1) >> a.ups) * a.in_units + uu) * Win + ((tx - 1) >> a.ups)) * 16;
+        }
+        asm volatile("" : "+v"(ry[k]), "+v"(rx[k]), "+v"(cst[k]));   // (kept in registers, not recomputed per tile)
+    }
+    // issue cursor: coordinates of the tile set up last, and what one step of nwg tiles adds to them
+    int c_tx, c_ty, c_n;
+    {
+        const int t0 = (int)blockIdx.x;
+        c_tx = t0 % a.tiles_x;
+        const int tr = t0 / a.tiles_x;
+        c_ty = tr % a.tiles_y;
+        c_n = tr / a.tiles_y;
+    }
+    const int d_tx = nwg % a.tiles_x, d_q = nwg / a.tiles_x;
+    const int d_ty = d_q % a.tiles_y, d_n = d_q / a.tiles_y;
     __amdgpu_buffer_rsrc_t in_rsrc, dy_rsrc;
     in_rsrc = dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in), 0, 0, 0x00020000);
-#define SR355_WG_SETUP(T_)                                                                              \
+#define SR355_WG_ADVANCE()                                                                              \
     {                                                                                                   \
-        const int txi = (T_) % a.tiles_x;                                                               \
-        const int tr = (T_) / a.tiles_x;                                                                \
-        const int tyi = tr % a.tiles_y;                                                                 \
-        const int n = tr / a.tiles_y;                                                                   \
-        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in) + (size_t)n * in_img_bytes, 0, \
+        c_tx += d_tx;                                                                                   \
+        const int cx_ = c_tx >= a.tiles_x;                                                              \
+        c_tx -= cx_ ? a.tiles_x : 0;                                                                    \
+        c_ty += d_ty + cx_;                                                                             \
+        const int cy_ = c_ty >= a.tiles_y;                                                              \
+        c_ty -= cy_ ? a.tiles_y : 0;                                                                    \
+        c_n += d_n + cy_;                                                                               \
+    }
+#define SR355_WG_SETUP()                                                                                \
+    {                                                                                                   \
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in) + (size_t)c_n * in_img_bytes, 0, \
                                                     in_img_bytes, 0x00020000);                          \
-        dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.dy) + (size_t)n * dy_img_bytes, 0, \
+        dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.dy) + (size_t)c_n * dy_img_bytes, 0, \
                                                     dy_img_bytes, 0x00020000);                          \
+        const int y0_ = c_ty * WTH, x0_ = c_tx * 32;   /* (multiples of 4 and 32: the shifts below split exactly) */ \
+        const int base_dy_ = (((y0_ >> a.dy_s2) * a.dy_units) * Wd + (x0_ >> a.dy_s2)) * 16;            \
+        const int base_in_ = (((y0_ >> a.ups) * a.in_units) * Win + (x0_ >> a.ups)) * 16;               \
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
             const int j = k * 3 + wave;                                                                 \
-            voff[k] = W_OOB;                                                                            \
-            if (SR355_EXP_WG_NOLOAD_V) continue;                                                        \
-            if (j < G::DY_I) {                                                                          \
-                const int i = j * 64 + lane; /* [u][py][px] */                                          \
-                const int u = i / WPX;                                                                  \
-                const int p = i - u * WPX;                                                              \
-                const int y = tyi * WTH + (p >> 5), x = txi * 32 + (p & 31);                            \
-                if (y < H && x < W && !(a.dy_s2 && ((y | x) & 1)))                                      \
-                    voff[k] = (((y >> a.dy_s2) * a.dy_units + a.dy_unit_off + u) * Wd + (x >> a.dy_s2)) * 16; \
-            } else if (j < G::JTOT) {                                                                   \
-                const int i = (j - G::DY_I) * 64 + lane; /* [u][ty][tx] haloed */                       \
-                const int u = i / WIPX;                                                                 \
-                const int p = i - u * WIPX;                                                             \
-                const int ty = p / 34;                                                                  \
-                const int tx = p - ty * 34;                                                             \
-                const int y = tyi * WTH - 1 + ty, x = txi * 32 - 1 + tx;                                \
-                const int uu = chunk * 4 + u;                                                           \
-                if (i < G::IN_ITEMS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && uu < a.in_units) \
-                    voff[k] = (((y >> a.ups) * a.in_units + uu) * Win + (x >> a.ups)) * 16;             \
-            }                                                                                           \
+            const int base_ = j < G::DY_I ? base_dy_ : base_in_;                                        \
+            const bool ok_ = (unsigned)(y0_ + ry[k]) < (unsigned)H && (unsigned)(x0_ + rx[k]) < (unsigned)W && \
+                             !SR355_EXP_WG_NOLOAD_V;                                                    \
+            voff[k] = ok_ ? base_ + cst[k] : W_OOB;                                                     \
         }                                                                                               \
     }
 #define SR355_WG_ISSUE(SLOT)                                                                            \
@@ -332,12 +367,13 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     static_assert(MB != 1 || G::JTOT % 3 == 0, "counted waits need equal DMA counts per wave");
     const int n_my = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
     if (n_my > 0) {
-        SR355_WG_SETUP((int)blockIdx.x);
+        SR355_WG_SETUP();
         SR355_WG_ISSUE(0);
     }
     constexpr int AHEAD = G::N_STAGES - 1;
     if (AHEAD > 1 && n_my > 1) {
-        SR355_WG_SETUP((int)blockIdx.x + nwg);
+        SR355_WG_ADVANCE();
+        SR355_WG_SETUP();
         SR355_WG_ISSUE(1);
     }
     int slot = 0;
@@ -349,7 +385,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         __builtin_amdgcn_s_barrier();
         if (it + AHEAD < n_my) {
             const int slot2 = slot + AHEAD >= G::N_STAGES ? slot + AHEAD - G::N_STAGES : slot + AHEAD;
-            SR355_WG_SETUP((int)blockIdx.x + (it + AHEAD) * nwg);
+            SR355_WG_ADVANCE();
+            SR355_WG_SETUP();
             SR355_WG_ISSUE(slot2);
         }
         const unsigned char *buf = smem + slot * G::STAGE_BYTES;
@@ -404,6 +441,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
 }
 
 #undef SR355_WG_SETUP
+#undef SR355_WG_ADVANCE
 #undef SR355_WG_ISSUE
 
 // Non-template entry points: hipcc (ROCm 7.2) emits no host stub for a kernel TEMPLATE whose body
