@@ -151,8 +151,15 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_void *)(smem + G::BIAS_OFF), 4, lane * 4, 0, 0, 0);
     }
 
-    // per-lane source offsets of this wave's DMA instructions (j = k*WAVES + wave)
-    int voff[G::KMAX];
+    // per-lane source offsets of this wave's DMA instructions (j = k*WAVES + wave).  What does not depend on the tile
+    // is computed once: for an activation item its position relative to the tile origin (row + 1 in the low half
+    // of `rel`, column + 1 in the high half; an item that never exists gets 0x7fff in both: an image's bytes fit 31
+    // bits, so no image has that many rows AND columns) and the part of its
+    // offset that position contributes (`cst`); weight items do not depend on the tile at all.  Per tile there remain
+    // two adds, two unsigned compares and a select per activation item, and the tile coordinates advance by the
+    // launch's stride without a division.
+    constexpr int KIN = (G::NIN_I + WAVES - 1) / WAVES;   // instructions of a wave that can be activation items
+    int voff[G::KMAX], rel[KIN], cst[KIN];
 #pragma unroll
     for (int k = 0; k < G::KMAX; ++k) {
         const int j = k * WAVES + wave;
@@ -165,32 +172,59 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int co = rem - tap * G::CO;
             voff[k] = ((u * 9 + tap) * a.cout_pad + co) * 16;
         }
+        if (k < KIN) {
+            rel[k < KIN ? k : 0] = 0x7fff7fff, cst[k < KIN ? k : 0] = 0;
+            if (j < G::NIN_I) {
+                const int i = j * 64 + lane;
+                const int u = i / G::NPIX;
+                const int p = i - u * G::NPIX;
+                const int ty = p / TWP;
+                const int tx = p - ty * TWP;
+                const bool exists = i < G::NIN && !SR355_DBG(a, 1) && !(a.zins && (((ty - 1) | (tx - 1)) & 1));
+                rel[k < KIN ? k : 0] = exists ? (ty | (tx << 16)) : 0x7fff7fff;
+                cst[k < KIN ? k : 0] = ((((ty - 1) >> a.ups) * a.in_units + u) * Win + ((tx - 1) >> a.ups)) * 16;
+            }
+            asm volatile("" : "+v"(rel[k < KIN ? k : 0]), "+v"(cst[k < KIN ? k : 0]));   // (kept, not recomputed per tile)
+        }
     }
     int in_lo = w_lo, in_hi = w_hi;   // base of the image the issue cursor is in
     int it_tile = 0, it_stage = 0;
-
-#define SR355_TILE_SETUP(ORD)                                                                         \
+    // tile coordinates of the issue cursor and of the tile whose epilogue comes next; one step of nwg tiles
+    int c_tx, c_ty, c_n;
+    {
+        c_tx = first % a.tiles_x;
+        const int tr_ = first / a.tiles_x;
+        c_ty = tr_ % a.tiles_y;
+        c_n = tr_ / a.tiles_y;
+    }
+    int e_tx = c_tx, e_ty = c_ty, e_n = c_n;
+    const int d_tx = nwg % a.tiles_x, d_q = nwg / a.tiles_x;
+    const int d_ty = d_q % a.tiles_y, d_n = d_q / a.tiles_y;
+#define SR355_TILE_STEP(TX, TY, NN)                                                                   \
     {                                                                                                 \
-        const int t_ = first + (ORD) * nwg;                                                           \
-        const int txi_ = t_ % a.tiles_x;                                                              \
-        const int tr_ = t_ / a.tiles_x;                                                               \
-        const int tyi_ = tr_ % a.tiles_y;                                                             \
-        const int n_ = tr_ / a.tiles_y;                                                               \
-        const unsigned long long ib_ = (unsigned long long)(a.in) + (size_t)n_ * img_bytes;           \
+        TX += d_tx;                                                                                   \
+        const int cx_ = TX >= a.tiles_x;                                                              \
+        TX -= cx_ ? a.tiles_x : 0;                                                                    \
+        TY += d_ty + cx_;                                                                             \
+        const int cy_ = TY >= a.tiles_y;                                                              \
+        TY -= cy_ ? a.tiles_y : 0;                                                                    \
+        NN += d_n + cy_;                                                                              \
+    }
+
+    // offsets of the tile at (c_tx, c_ty, c_n)
+#define SR355_TILE_SETUP()                                                                            \
+    {                                                                                                 \
+        const unsigned long long ib_ = (unsigned long long)(a.in) + (size_t)c_n * img_bytes;          \
         in_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)ib_);                                   \
         in_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib_ >> 32));                           \
-        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                         \
+        const int y0_ = c_ty * G::TH, x0_ = c_tx * 32;   /* (even: the shifts below split exactly) */ \
+        const int base_ = (((y0_ >> a.ups) * a.in_units) * Win + (x0_ >> a.ups)) * 16;                \
+        _Pragma("unroll") for (int k = 0; k < KIN; ++k) {                                             \
             const int j = k * WAVES + wave;                                                           \
             if (j < G::NIN_I) {                                                                       \
-                const int i = j * 64 + lane;                                                          \
-                const int u = i / G::NPIX;                                                            \
-                const int p = i - u * G::NPIX;                                                        \
-                const int ty = p / TWP;                                                               \
-                const int tx = p - ty * TWP;                                                          \
-                const int y = tyi_ * G::TH - 1 + ty, x = txi_ * 32 - 1 + tx;                          \
-                const bool valid = (i < G::NIN) && ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W) && \
-                                   !SR355_DBG(a, 1) && !(a.zins && ((y | x) & 1));                   \
-                voff[k] = valid ? (((y >> a.ups) * a.in_units + u) * Win + (x >> a.ups)) * 16 : OOB;  \
+                const int y = y0_ - 1 + (rel[k] & 0xffff), x = x0_ - 1 + (rel[k] >> 16);              \
+                const bool valid = ((unsigned)y < (unsigned)H) && ((unsigned)x < (unsigned)W);        \
+                voff[k] = valid ? base_ + cst[k] : OOB;                                               \
             }                                                                                         \
         }                                                                                             \
     }
@@ -223,11 +257,14 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 #define SR355_ISSUE_ADVANCE()                                                                         \
     if (it_tile < n_my && ++it_stage == S) {                                                          \
         it_stage = 0;                                                                                 \
-        if (++it_tile < n_my) SR355_TILE_SETUP(it_tile);                                              \
+        if (++it_tile < n_my) {                                                                       \
+            SR355_TILE_STEP(c_tx, c_ty, c_n);                                                         \
+            SR355_TILE_SETUP();                                                                       \
+        }                                                                                             \
     }
 
     SR355_FSTAMP(12);
-    if (n_my > 0) SR355_TILE_SETUP(0);
+    if (n_my > 0) SR355_TILE_SETUP();
     SR355_FSTAMP(13);
 #pragma unroll
     for (int g = 0; g < R - 1; ++g) {
@@ -324,12 +361,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
         if (++ct_stage == S) {
             // ---- epilogue of tile ct_tile ----
             if (ct_tile < 4) SR355_FSTAMP(3 + 2 * ct_tile);
-            const int t = first + ct_tile * nwg;
-            const int tx_i = t % a.tiles_x;
-            const int tr = t / a.tiles_x;
-            const int ty_i = tr % a.tiles_y;
-            const int n = tr / a.tiles_y;
-            const int x = tx_i * 32 + r;
+            const int ty_i = e_ty, n = e_n;
+            const int x = e_tx * 32 + r;
+            SR355_TILE_STEP(e_tx, e_ty, e_n);
             if (conv_epilogue_plain_ok(a)) {
                 if (a.f16_out)
                     conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
@@ -383,6 +417,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 #endif
 #undef SR355_RSRC
 #undef SR355_TILE_SETUP
+#undef SR355_TILE_STEP
 #undef SR355_ISSUE_DMA
 #undef SR355_ISSUE_ADVANCE
 #undef SR355_LOAD_FRAGS
