@@ -371,6 +371,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
                 else
                     conv_epilogue_tile_plain<MB, NB, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
                                                             cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if (conv_epilogue_plain_mask_ok(a)) {
+                conv_epilogue_tile_plain<MB, NB, false, true, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB,
+                                                                     x, cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if (conv_epilogue_plain_f32_ok(a)) {
+                conv_epilogue_tile_plain<MB, NB, false, false, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB,
+                                                                     x, cb * G::CO, h, !SR355_DBG(a, 2));
             } else if (MB == 1 && cb == 0 && conv_epilogue_rgb_ok(a)) {
                 if constexpr (MB == 1)
                     conv_epilogue_rgb<NB>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x, h, !SR355_DBG(a, 2));

@@ -126,50 +126,85 @@ __device__ __forceinline__ bool conv_epilogue_plain_ok(const ConvArgs &a) {
     return conv_epilogue_tile_ok(a) && a.out_act && !a.out_f32 && !a.mask_act && !a.res_act && !a.res1 && !a.res2 &&
            a.slope >= 0.f && a.slope <= 1.f;
 }
+// ... the same with the sign gate of a data gradient in front of the store (MASK), and with one fp32 output in place
+// of the 16-bit one (F32: a conv in front of a BatchNorm)
+__device__ __forceinline__ bool conv_epilogue_plain_mask_ok(const ConvArgs &a) {
+    return conv_epilogue_tile_ok(a) && a.out_act && !a.out_f32 && a.mask_act && !a.res_act && !a.res1 && !a.res2 &&
+           !a.f16_out && a.slope >= 0.f && a.slope <= 1.f;
+}
+__device__ __forceinline__ bool conv_epilogue_plain_f32_ok(const ConvArgs &a) {
+    return conv_epilogue_tile_ok(a) && !a.out_act && a.out_f32 && !a.mask_act && !a.res_act && !a.res1 && !a.res2 &&
+           a.slope >= 0.f && a.slope <= 1.f;
+}
 
-template <int MB, int NB, bool F16OUT>
+template <int MB, int NB, bool F16OUT, bool MASK = false, bool F32 = false>
 __device__ __forceinline__ void conv_epilogue_tile_plain(const ConvArgs &a, epi_f32x16 (&acc)[MB][NB],
                                                          const unsigned char *bias_lds, int n, int y0, int x, int cb_co,
                                                          int h, bool live) {
+    static_assert(!(F16OUT && (MASK || F32)) && !(MASK && F32), "one variant at a time");
     constexpr int OOB = 0x7fffff00;
     const int H = a.H, W = a.W;
     const int wstep = __builtin_amdgcn_readfirstlane(W * 16);          // bytes from one unit of a row to the next
-    const size_t img_bytes = (size_t)H * W * a.out_units * 16;
-    const unsigned long long p = (unsigned long long)a.out_act + (size_t)n * img_bytes;
-    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
-                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p)),
-        0, __builtin_amdgcn_readfirstlane((int)img_bytes), 0x00020000);
+    auto rsrc = [&](const void *base, size_t img_bytes) {
+        const unsigned long long p = (unsigned long long)base + (size_t)n * img_bytes;
+        return __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p)),
+            0, __builtin_amdgcn_readfirstlane((int)img_bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_out = F32 ? rsrc(a.out_f32, (size_t)H * W * a.f32_units * 16)
+                                              : rsrc(a.out_act, (size_t)H * W * a.out_units * 16);
+    const __amdgpu_buffer_rsrc_t rs_mk = rsrc(MASK ? a.mask_act : nullptr, (size_t)H * W * a.mask_units * 16);
     const float slope = a.slope;
+    [[maybe_unused]] const float mask_slope = a.mask_slope;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + (mb * 32 + q * 8 + h * 4) * 4);
+        for (int nb = 0; nb < NB; ++nb) {
+            const int y = y0 + nb;
+            const bool ok = live && x < W && y < H;
+            const int vo_act = ok ? ((y * a.out_units + a.out_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+            const int vo_f = ok ? ((y * a.f32_units + (cb_co >> 2) + h) * W + x) * 16 : OOB;
+            [[maybe_unused]] epi_v2u mk[4];
+            if constexpr (MASK) {
+                const int vo_mk = ok ? ((y * a.mask_units + a.mask_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int y = y0 + nb;
-                const bool ok = live && x < W && y < H;
-                const int vo_act = ok ? ((y * a.out_units + a.out_unit_off + (cb_co >> 3)) * W + x) * 16 + h * 8 : OOB;
+                for (int q = 0; q < 4; ++q)
+                    mk[q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo_mk, (mb * 4 + q) * wstep, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias_lds + (mb * 32 + q * 8 + h * 4) * 4);
                 float v[4] = {acc[mb][nb][4 * q + 0] + bv.x, acc[mb][nb][4 * q + 1] + bv.y,
                               acc[mb][nb][4 * q + 2] + bv.z, acc[mb][nb][4 * q + 3] + bv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], v[j] * slope);
-                epi_v2u o;
-                if constexpr (F16OUT) {
-                    epi_f16x4 pk;
+                if constexpr (MASK) {
+                    const epi_bf16x4 mv = __builtin_bit_cast(epi_bf16x4, mk[q]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
-                    o = __builtin_bit_cast(epi_v2u, pk);
-                } else {
-                    epi_bf16x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[j];
-                    o = __builtin_bit_cast(epi_v2u, pk);
+                    for (int j = 0; j < 4; ++j) v[j] = (float)mv[j] > 0.f ? v[j] : v[j] * mask_slope;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(o, rs_act, vo_act, (mb * 4 + q) * wstep, 0);
+                if constexpr (F32) {
+                    const epi_v4f of = {v[0], v[1], v[2], v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_out, vo_f,
+                                                           (mb * 8 + q * 2) * wstep, 0);
+                } else {
+                    epi_v2u o;
+                    if constexpr (F16OUT) {
+                        epi_f16x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (_Float16)fminf(fmaxf(v[j], -65504.f), 65504.f);
+                        o = __builtin_bit_cast(epi_v2u, pk);
+                    } else {
+                        epi_bf16x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk[j] = (__bf16)v[j];
+                        o = __builtin_bit_cast(epi_v2u, pk);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rs_out, vo_act, (mb * 4 + q) * wstep, 0);
+                }
             }
         }
     }
