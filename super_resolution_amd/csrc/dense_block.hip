@@ -393,22 +393,30 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(PTR))),         \
         0, __builtin_amdgcn_readfirstlane(LEN), 0x00020000)
 
-    // ---- pull the block's packed weights (468 KiB) into this XCD's L2 ahead of the ring.  Consecutive dense blocks
-    // use different weights, so the ring's first touch of every line would miss L2.  Workgroups b and b + 8 usually
-    // share an XCD (round-robin placement; a speed assumption only): the waves of such a group touch disjoint 1 KiB
-    // pieces, one dword per 16 bytes, and drop the result.
-    {
-        const int per_xcd = (gridDim.x + 7) >> 3;
-        const int gw = ((blockIdx.x >> 3) % per_xcd) * 4 + wave, stride = per_xcd * 4;
-#pragma unroll 1
-        for (int p = gw, it = 0; p < 468 && it < 16 && !DB_DEBUG(4); p += stride, ++it) {
-            const int j = p < 36 ? 0 : p < 90 ? 1 : p < 162 ? 2 : p < 252 ? 3 : 4;
-            const int start = j == 0 ? 0 : j == 1 ? 36 : j == 2 ? 90 : j == 3 ? 162 : 252;
-            const int len = (j == 4 ? 216 : 36 + 18 * j) * 1024;
-            // (an LDS-DMA into the dummy area: a load with a register destination would have to keep that register
-            // reserved until it lands)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(DB_RSRC(a.w[j], len), (lds_void *)(smem + DB_DUMMY_OFF), 4,
-                                                     (p - start) * 1024 + lane * 16, 0, 0, 0);
+    // ---- sign gates (data-gradient use): the saved activations at this wave's output pixels of the four growth steps,
+    // 4 channels x 4 quads per row.  Issued first: they come from HBM (written a whole forward pass ago) while the
+    // input tile was written by the launch before, and the sixty DMA instructions of the prologue take two
+    // microseconds to issue; the wait on them is the wait on the input tile, and no later use of them waits on the
+    // weight ring.
+    v2u mraw[4][3][4] = {};
+    if constexpr (GATED) {
+        const __amdgpu_buffer_rsrc_t rs_mk =
+            DB_RSRC(a.mask + (size_t)n * ((size_t)H * a.mask_units * W * 16), H * a.mask_units * W * 16);
+        const int q_step = __builtin_amdgcn_readfirstlane(W * 16);   // one unit further in the mask buffer
+#pragma unroll
+        for (int J = 1; J <= 4; ++J) {
+            int i0, nb;
+            wave_rows(rows_of(J), (J & 1) ? wave : 3 - wave, i0, nb);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < nb) {   // (wave-uniform)
+                    const int y = y0 - (5 - J) + i0 + i;
+                    const bool ok = y >= 0 && y < H && r < W;
+                    const int vo = ok ? ((y * a.mask_units + a.mask_off[J - 1]) * W + r) * 16 + h * 8 : DB_OOB;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mraw[J - 1][i][q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo, q * q_step, 0);
+                }
+            }
         }
     }
 
@@ -461,30 +469,26 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) db_issue_chunk(ring, a, smem, wave, ctx.pvoff);
 
-    // ---- sign gates (data-gradient use): the saved activations at this wave's output pixels of the four growth steps,
-    // 4 channels x 4 quads per row.  Loaded behind the prologue's DMA: the wait on them is the wait on the input tile,
-    // and no later use of them waits on the weight ring.
-    v2u mraw[4][3][4] = {};
-    if constexpr (GATED) {
-        const __amdgpu_buffer_rsrc_t rs_mk =
-            DB_RSRC(a.mask + (size_t)n * ((size_t)H * a.mask_units * W * 16), H * a.mask_units * W * 16);
-        const int q_step = __builtin_amdgcn_readfirstlane(W * 16);   // one unit further in the mask buffer
-#pragma unroll
-        for (int J = 1; J <= 4; ++J) {
-            int i0, nb;
-            wave_rows(rows_of(J), (J & 1) ? wave : 3 - wave, i0, nb);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (i < nb) {   // (wave-uniform)
-                    const int y = y0 - (5 - J) + i0 + i;
-                    const bool ok = y >= 0 && y < H && r < W;
-                    const int vo = ok ? ((y * a.mask_units + a.mask_off[J - 1]) * W + r) * 16 + h * 8 : DB_OOB;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mraw[J - 1][i][q] = __builtin_amdgcn_raw_buffer_load_b64(rs_mk, vo, q * q_step, 0);
-                }
-            }
+    // ---- pull the block's packed weights (468 KiB) into this XCD's L2 ahead of the ring (behind the input tile's
+    // and the ring's first requests: nothing waits for these).  Consecutive dense blocks
+    // use different weights, so the ring's first touch of every line would miss L2.  Workgroups b and b + 8 usually
+    // share an XCD (round-robin placement; a speed assumption only): the waves of such a group touch disjoint 1 KiB
+    // pieces, one dword per 16 bytes, and drop the result.
+    {
+        const int per_xcd = (gridDim.x + 7) >> 3;
+        const int gw = ((blockIdx.x >> 3) % per_xcd) * 4 + wave, stride = per_xcd * 4;
+#pragma unroll 1
+        for (int p = gw, it = 0; p < 468 && it < 16 && !DB_DEBUG(4); p += stride, ++it) {
+            const int j = p < 36 ? 0 : p < 90 ? 1 : p < 162 ? 2 : p < 252 ? 3 : 4;
+            const int start = j == 0 ? 0 : j == 1 ? 36 : j == 2 ? 90 : j == 3 ? 162 : 252;
+            const int len = (j == 4 ? 216 : 36 + 18 * j) * 1024;
+            // (an LDS-DMA into the dummy area: a load with a register destination would have to keep that register
+            // reserved until it lands)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(DB_RSRC(a.w[j], len), (lds_void *)(smem + DB_DUMMY_OFF), 4,
+                                                     (p - start) * 1024 + lane * 16, 0, 0, 0);
         }
     }
+
 
     // the input tile, the zero columns (and the gates) are in place before the first activation fragments are read
     // (the fragment prefetch of a step runs ahead of that step's first ring barrier)
