@@ -1551,8 +1551,9 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     upd(nf, nf, N, 2 * H, 2 * W);
     upd(nf, nf, N, 4 * H, 4 * W);
     upd(c.out_channels, nf, N, 4 * H, 4 * W);
-    const size_t block_slabs = wgrad_block_workspace_bytes(nf, gc, N, H, W);   // a dense block's five at once
-    if (block_slabs > slab) slab = block_slabs;
+    // a dense block's five at once, and three blocks' worth: an RRDB's reductions run as one launch
+    const size_t block_slabs = wgrad_block_workspace_bytes(nf, gc, N, H, W);
+    if (3 * block_slabs > slab) slab = 3 * block_slabs;
     b.slabs = take(slab);
     b.total = off;
     return b;
@@ -1755,6 +1756,9 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     }   // phase 0
     // RRDBs in reverse (:35-39, :18-24); the gradient-stack buffer alternates once per dense block
     int blocks_done = 0;   // dense blocks of this call whose wgrads have been issued
+    WgradReduceJob pending[15];
+    int n_pending = 0;
+    const size_t block_slab_floats = wgrad_block_workspace_bytes(nf, gc, N, H, W) / sizeof(float);
     for (int b = nb - 1; b >= 0; --b) {
         const int phase = nb - b;
         if (phase < phase_begin || phase >= phase_end) continue;
@@ -1809,7 +1813,16 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                 if (ss && (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
                            check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))
                     return SR355_ERR_HIP;
-                if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
+                // (the slab reductions of an RRDB's three blocks go out as one launch behind the third)
+                if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db,
+                                                slabs + (size_t)(n_pending / 5) * block_slab_floats, wstream,
+                                                pending + n_pending)))
+                    return rc;
+                n_pending += 5;
+                if (r == 0) {
+                    if ((rc = launch_wgrad_reduce_jobs(pending, n_pending, nf, gc, wstream))) return rc;
+                    n_pending = 0;
+                }
                 if (side_mark(par)) return SR355_ERR_HIP;
                 ++blocks_done;
                 cur = nxt;

@@ -454,12 +454,6 @@ __global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { 
 // One workgroup of 256 threads = 64 items x 4 waves; an item is four consecutive input channels of one (tap, output)
 // pair (one float4 of a slab row).  Wave k sums the slabs g = k, k + 4, ...; the four partial sums are added in wave
 // order through the LDS.  Bias items (one output channel each) follow the weight items.
-struct WgradReduceJob {
-    const float *slabs, *bias_slabs;
-    float *dw, *db;
-    int cout, cin, CO, G;
-    float scale;
-};
 __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceJob &j, int accumulate) {
     __shared__ float4 part[3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -650,8 +644,11 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
 // (growth convs, gc <= 32 outputs each, blockIdx.z = conv), conv5 (nf <= 64 outputs), one reduction.
 // `act` = the block's forward buffer, `stack` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
 // dw[k] / db[k] receive conv(k+1)'s gradients; conv5's is scaled by s5.
+// With `defer` (room for five jobs) the reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs
+// of several blocks, each of which then needs a slab area of its own until that launch.
 int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
-                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream) {
+                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
+                          WgradReduceJob *defer) {
     if (cout_pad_for(gc) != 32 || cout_pad_for(nf) > 64 || ((nf | gc) & 7)) {
         set_error("wgrad3x3 block: nf=%d gc=%d not supported", nf, gc);
         return SR355_ERR_UNSUPPORTED;
@@ -702,8 +699,24 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
     a.n_batch = 4 + n5;
     hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4 + n5), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
     if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
+    if (defer) {
+        for (int k = 0; k < 5; ++k) defer[k] = rt.j[k];
+        return SR355_OK;
+    }
+    return launch_wgrad_reduce_jobs(rt.j, 5, nf, gc, stream);
+}
+
+// One launch for the reductions of up to three dense blocks (blockIdx.y = job).
+int launch_wgrad_reduce_jobs(const WgradReduceJob *jobs, int n, int nf, int gc, hipStream_t stream) {
+    if (n < 1) return SR355_OK;
+    if (n > WGRAD_MAX_JOBS) {
+        set_error("wgrad reduce: %d jobs exceed one launch", n);
+        return SR355_ERR_INVALID;
+    }
+    WgradReduceTable rt;
+    for (int k = 0; k < n; ++k) rt.j[k] = jobs[k];
     const size_t biggest = (size_t)9 * nf * ((nf + 4 * gc + 3) / 4) + nf;
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(reduce_grid_for(biggest), 5), dim3(256), 0, stream, rt, 0);
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(reduce_grid_for(biggest), n), dim3(256), 0, stream, rt, 0);
     return check_hip(hipGetLastError(), "wgrad reduce batch launch");
 }
 

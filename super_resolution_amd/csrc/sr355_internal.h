@@ -185,8 +185,17 @@ int launch_pool2x2(const void *in, int N, int H, int W, int U, int dtype, const 
 size_t wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
 // All five weight / bias gradients of a dense block in three launches (see backward.hip).
 size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W);
+// One reduction of per-workgroup slabs into a conv's weight / bias gradient (see wgrad_reduce_body in backward.hip).
+struct WgradReduceJob {
+    const float *slabs, *bias_slabs;
+    float *dw, *db;
+    int cout, cin, CO, G;
+    float scale;
+};
 int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
-                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream);
+                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
+                          WgradReduceJob *defer = nullptr);
+int launch_wgrad_reduce_jobs(const WgradReduceJob *jobs, int n, int nf, int gc, hipStream_t stream);
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
                     hipStream_t stream, int dy_stride2 = 0);
