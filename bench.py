@@ -135,7 +135,7 @@ def conv_bytes(cin, cout, p_out, p_in=None, skips=0, f32_out=False, bf16_out=Tru
 def measured_traffic(symbol_fragment):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (the bench cannot run the
     profiler on itself); None when the file is absent or has no such kernel."""
-    path = os.path.join(ROOT, "profiles", "r02k_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02l_pmc_traffic.json")
     try:
         with open(path) as f:
             kernels = json.load(f)["kernels"]
@@ -184,7 +184,7 @@ def chain_roofline(net, x, rows, forwards=10):
             "kernel": "conv3x3_chain (the 345 body convs + trunk_conv as one persistent launch)",
             **first,
             "traffic": measured_traffic("conv3x3_chain"),
-            "traffic_source": "profiles/r02k_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
+            "traffic_source": "profiles/r02l_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
                               "rocprofv3 --pmc passes over this command; the committed summary, not a live reading)",
             "avg_launch_us": round(sec * 1e6, 1), "launches_per_forward": 1, "flop_per_launch": flop,
             "algorithmic_bytes_per_launch": round(nbytes),
@@ -221,7 +221,7 @@ def roofline_from(rows):
     roof = {"bound": "mfma", "kernel": names[dom], "achieved": round(d["achieved"], 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(d["achieved"] / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(symbols[dom]),
-            "traffic_source": "profiles/r02k_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
+            "traffic_source": "profiles/r02l_pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, separate "
                               "rocprofv3 --pmc passes; the committed summary, not a live reading)",
             "avg_launch_us": round(d["avg_launch_us"], 2), "launches_per_forward": d["launches_per_forward"],
             "flop_per_launch": d["flop_per_launch"], "algorithmic_bytes_per_launch": round(d["bytes_per_launch"]),

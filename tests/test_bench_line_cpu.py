@@ -1,5 +1,5 @@
 """CPU: the contract of bench.py's one JSON line, checked on the committed line of the final tree
-(profiles/r02k_bench.json) and on the roofline arithmetic bench.py applies (no GPU needed)."""
+(profiles/r02l_bench.json) and on the roofline arithmetic bench.py applies (no GPU needed)."""
 import json
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02k_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02l_bench.json")) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -40,7 +40,7 @@ def test_committed_bench_line_has_the_contract_fields():
 
 def test_committed_traffic_summary_is_what_the_line_quotes():
     d = _line()
-    with open(os.path.join(ROOT, "profiles", "r02k_pmc_traffic.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02l_pmc_traffic.json")) as f:
         kernels = json.load(f)["kernels"]
     chain = [v for k, v in kernels.items() if "conv3x3_chain" in k]
     assert len(chain) == 1
