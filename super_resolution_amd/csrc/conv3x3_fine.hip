@@ -91,10 +91,7 @@ struct FineGeo {
 };
 }  // namespace
 
-// EPI: 0 = every epilogue form, chosen per tile from the arguments; 1 / 2 = the launcher has checked that the lean
-// bias + LeakyReLU + bf16 (1) or fp16 (2) output form applies and the kernel holds nothing else (fewer live scalars in
-// the stage loop, a third less code).
-template <int MB, int NB, int R, int WPS, bool F16, int EPI = 0>
+template <int MB, int NB, int R, int WPS, bool F16>
 __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     typedef FineGeo<MB, NB, R> G;
     constexpr int WAVES = G::WAVES;
@@ -367,13 +364,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int ty_i = e_ty, n = e_n;
             const int x = e_tx * 32 + r;
             SR355_TILE_STEP(e_tx, e_ty, e_n);
-            if constexpr (EPI == 1) {
-                conv_epilogue_tile_plain<MB, NB, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
-                                                        cb * G::CO, h, !SR355_DBG(a, 2));
-            } else if constexpr (EPI == 2) {
-                conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
-                                                       cb * G::CO, h, !SR355_DBG(a, 2));
-            } else if (conv_epilogue_plain_ok(a)) {
+            if (conv_epilogue_plain_ok(a)) {
                 if (a.f16_out)
                     conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
                                                            cb * G::CO, h, !SR355_DBG(a, 2));
@@ -440,13 +431,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 #undef SR355_INTERLEAVE
 }
 
-template <int MB, int NB, int R, int WPS, bool F16, int EPI = 0>
+template <int MB, int NB, int R, int WPS, bool F16>
 static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     typedef FineGeo<MB, NB, R> G;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
-    auto kern = conv3x3_fine<MB, NB, R, WPS, F16, EPI>;
+    auto kern = conv3x3_fine<MB, NB, R, WPS, F16>;
     static std::atomic<bool> attr_done[64];         // (zero-initialised; acquire / release: threads may race here)
     static std::atomic<int> n_cu[64];
     int dev = 0;
@@ -478,24 +469,8 @@ static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     return check_hip(hipGetLastError(), "conv3x3 fine launch");
 }
 
-// (host-side twin of conv_epilogue_plain_ok)
-static bool plain_epilogue(const ConvArgs &a) {
-    return !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0 && a.out_act && !a.out_f32 && !a.mask_act && !a.res_act &&
-           !a.res1 && !a.res2 && a.slope >= 0.f && a.slope <= 1.f;
-}
-
-// LEAN: the lean-epilogue kernels exist for this tile shape (the shapes large images run on)
-template <int MB, int NB, int R, int WPS = 2, bool LEAN = false>
+template <int MB, int NB, int R, int WPS = 2>
 static int launch_fine_inst(const ConvArgs &a, hipStream_t stream) {
-    if constexpr (LEAN) {
-        if (plain_epilogue(a)) {
-            if (a.f16_in)
-                return a.f16_out ? launch_fine_typed<MB, NB, R, WPS, true, 2>(a, stream)
-                                 : launch_fine_typed<MB, NB, R, WPS, true, 1>(a, stream);
-            return a.f16_out ? launch_fine_typed<MB, NB, R, WPS, false, 2>(a, stream)
-                             : launch_fine_typed<MB, NB, R, WPS, false, 1>(a, stream);
-        }
-    }
     return a.f16_in ? launch_fine_typed<MB, NB, R, WPS, true>(a, stream)
                     : launch_fine_typed<MB, NB, R, WPS, false>(a, stream);
 }
@@ -504,7 +479,7 @@ static int launch_fine_inst(const ConvArgs &a, hipStream_t stream) {
 int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     ConvArgs b = a;
     b.trace = g_conv_trace;
-    if ((a.cout_pad % 64) == 0) return launch_fine_inst<2, 2, 2, 2, true>(b, stream);
+    if ((a.cout_pad % 64) == 0) return launch_fine_inst<2, 2, 2>(b, stream);
     // 32 output channels: a wave's MFMA run per stage is short, and the barrier plus the first fragment reads of
     // every stage are exposed; 16-row tiles double the run (and halve the weight traffic per pixel) wherever they
     // still give every CU a tile
@@ -521,7 +496,7 @@ int launch_conv3x3_fine(const ConvArgs &a, hipStream_t stream) {
     const int cu = cu_of[dev].load(std::memory_order_acquire);
     const long long tiles16 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 15) / 16);
     static const int force_nb = [] { const char *e = getenv("SR355_NARROW_NB"); return e ? atoi(e) : 0; }();
-    if (force_nb == 4 || (force_nb == 0 && tiles16 >= cu)) return launch_fine_inst<1, 4, 2, 2, true>(b, stream);
+    if (force_nb == 4 || (force_nb == 0 && tiles16 >= cu)) return launch_fine_inst<1, 4, 2>(b, stream);
     return launch_fine_inst<1, 2, 3>(b, stream);
 }
 
