@@ -1,0 +1,69 @@
+"""GPU: run-to-run reproducibility.  The reference trains with cuDNN's default (non-deterministic) algorithms
+(/root/reference/esrgan/train.py:196-223); here every kernel sums in a fixed order, so repeating a backward pass from
+the same state must give the same bits — whatever ran before it and whatever the allocator's free blocks hold.  The
+sequence below (discriminator prefixes of growing depth, free memory refilled with noise in between) is the one that
+exposed a kernel build whose results depended on what the preceding launches had left behind."""
+import copy
+
+import pytest
+import torch
+
+from oracle import esrgan_oracle as O
+import super_resolution_amd as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _junk():
+    blocks = [torch.empty(mb * 1024 * 256, device=DEV).normal_() for mb in (256, 64, 16, 4, 1)]
+    torch.cuda.synchronize()
+    del blocks
+
+
+def test_discriminator_prefix_backwards_repeat_bit_for_bit():
+    netD = S.Discriminator()
+    netD.load_state_dict(O.make_discriminator_state(102))
+    netD = netD.to(DEV).train()
+    hr = torch.rand(16, 3, 128, 128, generator=torch.Generator().manual_seed(104)).to(DEV)
+    for k in (2, 5, 8, 11, 23):                       # the prefix ends with conv k as its (activation-free) last layer
+        sub = copy.copy(netD)
+        sub.__dict__ = dict(netD.__dict__)
+        sub._modules = dict(netD._modules)
+        sub._modules["model"] = netD.model[:k + 1]
+        ref = None
+        for rep in range(6):
+            if rep % 3 == 0:
+                _junk()
+            sub.zero_grad(set_to_none=True)
+            x = hr.clone().requires_grad_(True)
+            sub(x).square().mean().backward()
+            torch.cuda.synchronize()
+            got = {"x": x.grad.clone()}
+            got.update({n: p.grad.clone() for n, p in sub.named_parameters() if p.grad is not None})
+            if ref is None:
+                ref = got
+                continue
+            bad = [n for n in ref if not torch.equal(ref[n], got[n])]
+            assert not bad, f"prefix {k} repetition {rep}: " + " ".join(bad)
+
+
+def test_generator_training_step_repeats_bit_for_bit():
+    sd = O.make_generator_state(7, num_blocks=3)
+    g = torch.Generator().manual_seed(8)
+    lr, hr = torch.rand(16, 3, 32, 32, generator=g).to(DEV), torch.rand(16, 3, 128, 128, generator=g).to(DEV)
+    ref = None
+    for rep in range(4):
+        _junk()
+        net = S.GeneratorRRDB(num_blocks=3)
+        net.load_state_dict(sd)
+        net = net.to(DEV).train()
+        opt = S.FlatAdam(net.parameters(), lr=1e-4)
+        for _ in range(2):
+            S.pixel_step(net, opt, lr, hr)
+        torch.cuda.synchronize()
+        got = [p.detach().clone() for p in net.parameters()]
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), rep
