@@ -91,7 +91,10 @@ struct FineGeo {
 };
 }  // namespace
 
-template <int MB, int NB, int R, int WPS, bool F16>
+// EPI (diagnostic builds, -DSR355_LEAN_INST): 0 = every epilogue form, chosen per tile from the arguments; 1 / 2 = the
+// launcher has checked that the lean bias + LeakyReLU + bf16 (1) / fp16 (2) output form applies and the kernel holds
+// nothing else (143 registers instead of 241: a different schedule of the same arithmetic, used to screen for races).
+template <int MB, int NB, int R, int WPS, bool F16, int EPI = 0>
 __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
     typedef FineGeo<MB, NB, R> G;
     constexpr int WAVES = G::WAVES;
@@ -364,7 +367,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
             const int ty_i = e_ty, n = e_n;
             const int x = e_tx * 32 + r;
             SR355_TILE_STEP(e_tx, e_ty, e_n);
-            if (conv_epilogue_plain_ok(a)) {
+            if constexpr (EPI == 1) {
+                conv_epilogue_tile_plain<MB, NB, false>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
+                                                        cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if constexpr (EPI == 2) {
+                conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
+                                                       cb * G::CO, h, !SR355_DBG(a, 2));
+            } else if (conv_epilogue_plain_ok(a)) {
                 if (a.f16_out)
                     conv_epilogue_tile_plain<MB, NB, true>(a, acc, smem + G::BIAS_OFF, n, ty_i * G::TH + wave * NB, x,
                                                            cb * G::CO, h, !SR355_DBG(a, 2));
@@ -431,13 +440,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_fine(const ConvArgs a) {
 #undef SR355_INTERLEAVE
 }
 
-template <int MB, int NB, int R, int WPS, bool F16>
+template <int MB, int NB, int R, int WPS, bool F16, int EPI = 0>
 static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     typedef FineGeo<MB, NB, R> G;
     ConvArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
-    auto kern = conv3x3_fine<MB, NB, R, WPS, F16>;
+    auto kern = conv3x3_fine<MB, NB, R, WPS, F16, EPI>;
     static std::atomic<bool> attr_done[64];         // (zero-initialised; acquire / release: threads may race here)
     static std::atomic<int> n_cu[64];
     int dev = 0;
@@ -469,8 +478,27 @@ static int launch_fine_typed(const ConvArgs &a0, hipStream_t stream) {
     return check_hip(hipGetLastError(), "conv3x3 fine launch");
 }
 
+#ifdef SR355_LEAN_INST
+// (host-side twin of conv_epilogue_plain_ok)
+static bool plain_epilogue(const ConvArgs &a) {
+    return !a.out_nchw && !a.out_u8 && (a.cout_real & 31) == 0 && a.out_act && !a.out_f32 && !a.mask_act && !a.res_act &&
+           !a.res1 && !a.res2 && a.slope >= 0.f && a.slope <= 1.f;
+}
+#endif
+
 template <int MB, int NB, int R, int WPS = 2>
 static int launch_fine_inst(const ConvArgs &a, hipStream_t stream) {
+#ifdef SR355_LEAN_INST
+    if constexpr (NB >= 2 && R == 2) {
+        if (plain_epilogue(a)) {
+            if (a.f16_in)
+                return a.f16_out ? launch_fine_typed<MB, NB, R, WPS, true, 2>(a, stream)
+                                 : launch_fine_typed<MB, NB, R, WPS, true, 1>(a, stream);
+            return a.f16_out ? launch_fine_typed<MB, NB, R, WPS, false, 2>(a, stream)
+                             : launch_fine_typed<MB, NB, R, WPS, false, 1>(a, stream);
+        }
+    }
+#endif
     return a.f16_in ? launch_fine_typed<MB, NB, R, WPS, true>(a, stream)
                     : launch_fine_typed<MB, NB, R, WPS, false>(a, stream);
 }

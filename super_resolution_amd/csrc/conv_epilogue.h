@@ -17,6 +17,20 @@ typedef unsigned int epi_v2u __attribute__((ext_vector_type(2)));
 typedef unsigned int epi_v4u __attribute__((ext_vector_type(4)));
 typedef float epi_v4f __attribute__((ext_vector_type(4)));
 
+// 16-byte buffer store at byte offset `voffset + uoffset` (per-lane + wave-uniform part).  The uniform part is added to
+// the vector offset and the instruction's scalar offset stays the immediate 0 on purpose: a store of more than 64 bits
+// keeps reading its data registers after it has issued, and the two wait states the ISA asks for before a VALU
+// instruction may overwrite them are inserted by hipcc (ROCm 7.2) only for that form.  With the uniform part in an SGPR
+// scalar offset the compiler's hazard recogniser exempts the store, the register allocator reuses the first data
+// register in the very next instruction, and gfx950 then stores a few lanes of the NEW value: the discriminator's
+// 64 -> 128 conv came out with wrong first channels of some quads about once in forty launches on a cold memory system
+// (tools/diag_layers.py found the launch, tools/check_store_hazard.py finds the instruction pairs in the code object).
+// An out-of-range `voffset` (0x7fffff00) stays out of range: the sum is below 2^32 and above any buffer's size.
+template <int AUX = 0>
+__device__ __forceinline__ void epi_store_b128(epi_v4u data, __amdgpu_buffer_rsrc_t rsrc, int voffset, int uoffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset + uoffset, 0, AUX);
+}
+
 // w * r + s * v, written once so that every epilogue path rounds it the same way
 __device__ __forceinline__ float epi_axpby(float w, float r, float s, float v) { return __builtin_fmaf(w, r, s * v); }
 
@@ -188,8 +202,7 @@ __device__ __forceinline__ void conv_epilogue_tile_plain(const ConvArgs &a, epi_
                 }
                 if constexpr (F32) {
                     const epi_v4f of = {v[0], v[1], v[2], v[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_out, vo_f,
-                                                           (mb * 8 + q * 2) * wstep, 0);
+                    epi_store_b128(__builtin_bit_cast(epi_v4u, of), rs_out, vo_f, (mb * 8 + q * 2) * wstep);
                 } else {
                     epi_v2u o;
                     if constexpr (F16OUT) {
@@ -337,8 +350,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs &a, epi_f32x16
                 }
                 if (a.out_f32) {
                     const epi_v4f of = {v[0], v[1], v[2], v[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_v4u, of), rs_f32, vo_f,
-                                                           (mb * 8 + q * 2) * wstep, AUX);
+                    epi_store_b128<AUX>(__builtin_bit_cast(epi_v4u, of), rs_f32, vo_f, (mb * 8 + q * 2) * wstep);
                 }
                 if (a.out_act) {
                     epi_v2u o;
