@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 13
+#define SR355_ABI_VERSION 14
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -326,6 +326,19 @@ int sr355_generator_forward_u8(const sr355_generator_cfg *cfg, const void *packe
  * device and returns the kernel's duration in milliseconds (a negative value if none was recorded). */
 void sr355_chain_timing(int on);
 float sr355_chain_last_ms(void);
+
+/* Health of that persistent launch (again without a counterpart in the reference, whose convs are separate launches,
+ * esrgan_model.py:55-58).  Its workgroups wait for each other and must all be resident; where they cannot be (a
+ * second process on the GPU, masked CUs) a wait gives up after two seconds, the forward's output is INVALID and the
+ * kernel raises a word that the library copies back behind the launch.  sr355_chain_status(wait) answers for the most
+ * recent such forward on the current device: SR355_OK, SR355_CHAIN_PENDING (wait == 0 only: the launch has not finished
+ * yet) or, once per failed launch, SR355_ERR_HIP with the reason in sr355_last_error().  wait != 0 blocks until the
+ * launch and the copy have completed: call it before consuming the output of a one-shot forward.  The next forward call
+ * makes the same check without blocking.  After a failure the device runs the body as one launch per conv (slower,
+ * no residency requirement) until sr355_chain_reenable(). */
+#define SR355_CHAIN_PENDING 1
+int sr355_chain_status(int wait);
+void sr355_chain_reenable(void);
 
 /* One Adam update over flat fp32 device buffers of n elements, in one launch: the arithmetic of
  * torch.optim.Adam(lr, betas) as the reference configures it (/root/reference/esrgan/train.py:117-122; no amsgrad,

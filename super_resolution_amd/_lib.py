@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -33,7 +33,7 @@ EXPORTS = (
     "sr355_conv3x3_wgrad_static", "sr355_wgrad_f32_workspace_bytes", "sr355_conv3x3_wgrad_f32",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
-    "sr355_chain_timing", "sr355_chain_last_ms",
+    "sr355_chain_timing", "sr355_chain_last_ms", "sr355_chain_status", "sr355_chain_reenable",
     "sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes", "sr355_generator_forward_train",
     "sr355_generator_packed_bwd_bytes", "sr355_generator_pack_bwd", "sr355_generator_bwd_workspace_bytes",
     "sr355_generator_grads_floats", "sr355_generator_backward",
@@ -170,6 +170,9 @@ def lib() -> C.CDLL:
     L.sr355_chain_timing.restype = None
     L.sr355_chain_last_ms.argtypes = []
     L.sr355_chain_last_ms.restype = C.c_float
+    L.sr355_chain_status.argtypes = [i]
+    L.sr355_chain_reenable.argtypes = []
+    L.sr355_chain_reenable.restype = None
     cfgp = C.POINTER(GeneratorCfg)
     for name in ("sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes",
                  "sr355_generator_bwd_workspace_bytes"):

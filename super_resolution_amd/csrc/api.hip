@@ -820,17 +820,6 @@ static bool use_dense_fused(const sr355_generator_cfg *cfg, int N, int H, int W)
     return (long long)N * ((H + 1) / 2) <= max_bands;
 }
 
-// The body (every dense block and trunk_conv) as one persistent launch (conv3x3_chain.hip) where 16-row tiles give every
-// CU work: large batches / images.  SR355_CHAIN=0 keeps one launch per conv.
-static bool use_chain(const sr355_generator_cfg *cfg, int N, int H, int W) {
-    const char *e = getenv("SR355_CHAIN");      // read on every call: tests compare the two paths in one process
-    const int knob = e ? atoi(e) : 1;
-    if (!knob || cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features != 64 || cfg->growth_channels != 32) return false;
-    int slots = 0;
-    if (chain_resident_workgroups(&slots) || slots < 2) return false;
-    return (long long)N * ((H + CHAIN_TILE_ROWS - 1) / CHAIN_TILE_ROWS) * ((W + 31) / 32) >= slots / CHAIN_WG_PER_CU;
-}
-
 // The word the chain kernel raises when a wait gave up, copied back after every chain launch and looked at by the
 // next call: pinned host memory, one word per device.
 static unsigned *chain_err_host(int dev) {
@@ -855,15 +844,70 @@ struct ChainOrder {
     std::mutex m;
     hipEvent_t done = nullptr;
     bool recorded = false;
+    hipEvent_t err_copied = nullptr;     // recorded behind the copy of the kernel's error word to the pinned host word
+    bool err_recorded = false;
+    std::atomic<bool> disabled{false};   // a launch gave up once: this device runs one launch per conv from then on
 };
 static ChainOrder *chain_order(int dev) {
     static std::once_flag once[64];
     static ChainOrder ord[64];
     if (dev < 0 || dev >= 64) return nullptr;
     std::call_once(once[dev], [dev] {
-        if (hipEventCreateWithFlags(&ord[dev].done, hipEventDisableTiming) != hipSuccess) ord[dev].done = nullptr;
+        if (hipEventCreateWithFlags(&ord[dev].done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ord[dev].err_copied, hipEventDisableTiming) != hipSuccess)
+            ord[dev].done = nullptr;
     });
     return ord[dev].done ? &ord[dev] : nullptr;
+}
+
+// The body (every dense block and trunk_conv) as one persistent launch (conv3x3_chain.hip) where 16-row tiles give every
+// CU work: large batches / images.  SR355_CHAIN=0 keeps one launch per conv.
+static bool use_chain(const sr355_generator_cfg *cfg, int N, int H, int W) {
+    const char *e = getenv("SR355_CHAIN");      // read on every call: tests compare the two paths in one process
+    const int knob = e ? atoi(e) : 1;
+    if (!knob || cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features != 64 || cfg->growth_channels != 32) return false;
+    int slots = 0, dev = 0;
+    if (chain_resident_workgroups(&slots) || slots < 2) return false;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        ChainOrder *order = chain_order(dev);
+        if (order && order->disabled.load(std::memory_order_relaxed)) return false;
+    }
+    return (long long)N * ((H + CHAIN_TILE_ROWS - 1) / CHAIN_TILE_ROWS) * ((W + 31) / 32) >= slots / CHAIN_WG_PER_CU;
+}
+
+// Whether the most recent chain launch on `dev` gave up a wait (its output is then invalid).  wait: block until that
+// launch and the copy of its error word have completed; otherwise answer from what has completed so far.  A launch that
+// gave up is reported once (SR355_ERR_HIP, with the reason) and switches the device to one launch per conv: the
+// workgroups of the persistent launch evidently cannot all be resident here (another process on the GPU, masked CUs).
+static int chain_status_of(int dev, bool wait) {
+    ChainOrder *order = chain_order(dev);
+    unsigned *err_host = chain_err_host(dev);
+    if (!order || !err_host) return SR355_OK;
+    std::lock_guard<std::mutex> lock(order->m);
+    if (order->err_recorded) {
+        if (wait) {
+            if (check_hip(hipEventSynchronize(order->err_copied), "hipEventSynchronize")) return SR355_ERR_HIP;
+        } else if (hipEventQuery(order->err_copied) != hipSuccess) {
+            return SR355_CHAIN_PENDING;
+        }
+    }
+    if (*(volatile unsigned *)err_host) {
+        *(volatile unsigned *)err_host = 0;
+        order->disabled.store(true, std::memory_order_relaxed);
+        set_error("generator forward: the body's persistent launch gave up waiting for a workgroup that never became "
+                  "resident (is another process using this GPU?); that forward's output is invalid; this device now runs "
+                  "one launch per conv");
+        return SR355_ERR_HIP;
+    }
+    return SR355_OK;
+}
+
+// SR355_CHAIN_GRID=<n> (read on every call, tests only): launch the persistent kernel with exactly n workgroups even
+// if they cannot all be resident, which is how the give-up path of its waits is exercised.
+static int chain_grid_knob() {
+    const char *e = getenv("SR355_CHAIN_GRID");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? -n : 0;
 }
 
 // Optional events around the chain launch (sr355_chain_timing / sr355_chain_last_ms).
@@ -1122,12 +1166,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         int dev = 0;
         if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
         unsigned *err_host = chain_err_host(dev);
-        if (err_host && *(volatile unsigned *)err_host) {
-            *(volatile unsigned *)err_host = 0;
-            set_error("generator forward: the previous call's chain kernel gave up waiting for a workgroup (its output "
-                      "was invalid)");
-            return SR355_ERR_HIP;
-        }
+        if (chain_status_of(dev, false) == SR355_ERR_HIP) return SR355_ERR_HIP;   // (the device now runs one launch per conv)
         if (check_hip(hipMemcpyAsync(fb.chain_table, passes.data(), passes.size() * sizeof(ChainPass),
                                      hipMemcpyHostToDevice, stream), "hipMemcpyAsync") ||
             check_hip(hipMemsetAsync(fb.chain_flags, 0, fb.chain_flag_bytes, stream), "hipMemsetAsync"))
@@ -1158,7 +1197,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             if (order->recorded && check_hip(hipStreamWaitEvent(stream, order->done, 0), "hipStreamWaitEvent"))
                 return SR355_ERR_HIP;
             if (cev && check_hip(hipEventRecord(cev->before, stream), "hipEventRecord")) return SR355_ERR_HIP;
-            if ((rc = launch_conv3x3_chain(ca, 0, stream))) return rc;
+            if ((rc = launch_conv3x3_chain(ca, chain_grid_knob(), stream))) return rc;
             if (cev) {
                 if (check_hip(hipEventRecord(cev->after, stream), "hipEventRecord")) return SR355_ERR_HIP;
                 cev->recorded = true;
@@ -1200,8 +1239,13 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             }
         }
 #endif
-        if (err_host && check_hip(hipMemcpyAsync(err_host, ca.err, 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"))
-            return SR355_ERR_HIP;
+        if (err_host) {
+            std::lock_guard<std::mutex> lock(order->m);
+            if (check_hip(hipMemcpyAsync(err_host, ca.err, 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync") ||
+                check_hip(hipEventRecord(order->err_copied, stream), "hipEventRecord"))
+                return SR355_ERR_HIP;
+            order->err_recorded = true;
+        }
     }
     // nearest x2 + upconv1 + lrelu (:59), nearest x2 + upconv2 + lrelu (:60)
     if ((rc = conv(fb.L1, ws.nf_units, ws.nf_units, 2 * H, 2 * W, 1, fb.H1, ws.nf_units, 0, 0.2f, nullptr, 0.f,
@@ -1308,6 +1352,18 @@ float sr355_chain_last_ms(void) {
     if (hipEventSynchronize(cev->after) != hipSuccess || hipEventElapsedTime(&ms, cev->before, cev->after) != hipSuccess)
         return -1.f;
     return ms;
+}
+
+int sr355_chain_status(int wait) {
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
+    return chain_status_of(dev, wait != 0);
+}
+
+void sr355_chain_reenable(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (ChainOrder *order = chain_order(dev)) order->disabled.store(false, std::memory_order_relaxed);
 }
 
 int sr355_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,

@@ -746,6 +746,7 @@ int launch_conv3x3_chain(const ChainArgs &c0, int max_workgroups, hipStream_t st
     int slots = 0;
     if (int rc = chain_resident_workgroups(&slots)) return rc;
     if (max_workgroups > 0 && slots > max_workgroups) slots = max_workgroups;
+    if (max_workgroups < 0) slots = -max_workgroups;      // forced grid (may exceed what is resident: the waits then give up)
     if (slots < 1) {
         set_error("conv3x3 chain: no resident workgroup slot");
         return SR355_ERR_UNSUPPORTED;

@@ -15,6 +15,7 @@ There is no CPU path: tensors must live on a ROCm device.
 from __future__ import annotations
 
 import operator
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -22,7 +23,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import fp32_train, ops
-from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB
+from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB, Sr355Error
 
 _PRECISIONS = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32, "f32": DTYPE_F32}
 _VERSION_OF = operator.attrgetter("_version")
@@ -228,13 +229,19 @@ class GeneratorRRDB(nn.Module):
     flat buffer, instead of handing 702 gradients to autograd's per-parameter accumulation: the same ``.grad``
     fields after ``loss.backward()`` (optimizers, ``GradScaler``, gradient accumulation see no difference) at a
     third of the host time of a small-patch step.  Pass ``False`` to keep per-parameter autograd edges
-    (``torch.autograd.grad(loss, netG.parameters())``, tensor hooks on the parameters)."""
+    (``torch.autograd.grad(loss, netG.parameters())``, tensor hooks on the parameters).
+    ``checked``: a no-grad forward of a large batch / image runs its body as one persistent launch whose workgroups
+    must all be resident on the GPU; if another process holds part of the GPU its waits give up and the output is
+    invalid, which an unchecked forward reports only on the NEXT call (or through ``ops.chain_status()``).  With
+    ``checked=True`` every such forward waits for its launch, and one that gave up is run again as one launch per conv
+    (a warning says so): the call returns a valid result at the price of one host synchronisation per forward."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, num_features: int = 64,
                  num_blocks: int = 23, growth_channels: int = 32, *, precision: str = "bf16",
                  hr_split: bool = True, direct_grads: bool = True, hr_f16: bool = True,
-                 dense_skip_fp32: bool = False):
+                 dense_skip_fp32: bool = False, checked: bool = False):
         super().__init__()
+        self.checked = bool(checked)
         self.hr_split = bool(hr_split)
         self.hr_f16 = bool(hr_f16)
         self.dense_skip_fp32 = bool(dense_skip_fp32)
@@ -334,8 +341,20 @@ class GeneratorRRDB(nn.Module):
                 return fp32_train.generator_forward(self, xin)
             return _GeneratorFunction.apply(xin, self, None, *_graph_params(self, params))
         N, _c, H, W = xin.shape
-        return ops.generator_forward(xin.detach(), self.packed_parameters(True), self.workspace(N, H, W, xin.device),
-                                     self.cfg(True))
+        return self._checked(xin.device, lambda: ops.generator_forward(
+            xin.detach(), self.packed_parameters(True), self.workspace(N, H, W, xin.device), self.cfg(True)))
+
+    def _checked(self, device, run):
+        """``run()``; with ``checked`` also wait for the body's persistent launch and, if it gave up, run again (the
+        library has switched the device to one launch per conv by then)."""
+        out = run()
+        if getattr(self, "checked", False):
+            try:
+                ops.chain_status(True, device)
+            except Sr355Error as exc:
+                warnings.warn(f"{exc}; the forward was repeated as one launch per conv")
+                out = run()
+        return out
 
     @torch.no_grad()
     def upscale_u8(self, image: Tensor) -> Tensor:
@@ -353,8 +372,8 @@ class GeneratorRRDB(nn.Module):
             raise RuntimeError("super_resolution_amd runs on ROCm devices only: move the image to 'cuda' "
                                "(there is no CPU fallback)")
         N, H, W, _c = img.shape
-        out = ops.generator_forward_u8(img.contiguous(), self.packed_parameters(True),
-                                       self.workspace(N, H, W, img.device), self.cfg(True))
+        out = self._checked(img.device, lambda: ops.generator_forward_u8(
+            img.contiguous(), self.packed_parameters(True), self.workspace(N, H, W, img.device), self.cfg(True)))
         return out[0] if single else out
 
 

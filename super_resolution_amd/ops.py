@@ -810,6 +810,28 @@ def now(op):
     return getattr(op, "_init_fn", op)
 
 
+def chain_status(wait: bool = True, device=None) -> bool:
+    """Health of the most recent whole-generator forward that ran its body as ONE persistent launch on ``device``
+    (default: the current one).  That launch needs all its workgroups resident; where they cannot be (a second
+    process on the GPU) a wait gives up after two seconds and the forward's output is invalid.  Returns True when the
+    launch completed soundly (or none ran), False when ``wait`` is False and it has not finished yet; raises
+    ``Sr355Error`` once for a launch that gave up — the device then runs one launch per conv
+    (``chain_reenable()`` undoes that).  ``wait=True`` blocks until the launch has completed: use it before trusting
+    the output of a one-shot forward."""
+    with _on(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)):
+        rc = _lib.lib().sr355_chain_status(1 if wait else 0)
+    if rc == 1:
+        return False
+    check(rc, "sr355_chain_status")
+    return True
+
+
+def chain_reenable(device=None) -> None:
+    """Let the body run as one persistent launch again on ``device`` after a launch that gave up."""
+    with _on(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)):
+        _lib.lib().sr355_chain_reenable()
+
+
 conv3x3_fwd_now = now(conv3x3_fwd)
 bn_lrelu_fwd_now = now(bn_lrelu_fwd)
 bn_lrelu_bwd_now = now(bn_lrelu_bwd)

@@ -82,3 +82,26 @@ def test_bad_arguments_are_rejected_without_touching_a_device(L):
     assert L.sr355_conv3x3_fwd(C.byref(a), None) == -1
     cfg = GeneratorCfg(3, 3, 64, 1, 32, _lib.DTYPE_BF16, 1, 0)
     assert L.sr355_generator_forward(C.byref(cfg), None, 0, None, None, 1, 8, 8, None, 0, None) == -1
+
+
+def test_integration_snippet_quotes_the_header_constants():
+    """The ctypes stub in INTEGRATION.md is what a maintainer pastes: its ABI version, dtype code and config fields must
+    be the header's."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "sr355.h")).read()
+    abi = int(re.search(r"#define SR355_ABI_VERSION (\d+)", hdr).group(1))
+    bf16 = int(re.search(r"#define SR355_DTYPE_BF16 (\d+)", hdr).group(1))
+    f32 = int(re.search(r"#define SR355_DTYPE_F32 (\d+)", hdr).group(1))
+    assert int(re.search(r"sr355_abi_version\(\) == (\d+)", doc).group(1)) == abi
+    m = re.search(r"cfg = Cfg\(([\d, ]+)\)\s*# dtype (\d+) = SR355_DTYPE_BF16 \((\d+) = SR355_DTYPE_F32\)", doc)
+    assert m, "the snippet's Cfg(...) line with its dtype comment"
+    values = [int(v) for v in m.group(1).split(",")]
+    fields = re.search(r'for n in \(([^)]*)\)\]', doc, re.S).group(1)
+    names = re.findall(r'"(\w+)"', fields)
+    struct = re.search(r"typedef struct sr355_generator_cfg \{(.*?)\} sr355_generator_cfg;", hdr, re.S).group(1)
+    struct = re.sub(r"/\*.*?\*/", "", struct, flags=re.S)
+    declared = [n.strip() for decl in struct.split(";") if decl.strip() for n in decl.replace("int", "").split(",")]
+    assert names == declared and len(values) == len(names)
+    assert values[names.index("dtype")] == bf16 == int(m.group(2)) and int(m.group(3)) == f32

@@ -60,3 +60,45 @@ def test_full_depth_chain_matches_and_repeats():
     finally:
         os.environ.pop("SR355_CHAIN", None)
     assert torch.equal(net.upscale_u8(img), ref8)
+
+
+def test_a_launch_that_gives_up_is_reported_on_the_same_call_path_and_retried(monkeypatch):
+    """The body's persistent launch needs every workgroup resident.  Forced to a grid that cannot be (one workgroup per
+    tile of an image with more tiles than slots, so that resident tiles border tiles that are not: SR355_CHAIN_GRID),
+    its waits give up after two seconds.  The status call
+    then reports that launch (once), the device falls back to one launch per conv, and a ``checked`` module returns the
+    valid result from the same call."""
+    import warnings
+    from super_resolution_amd import ops
+    from super_resolution_amd._lib import Sr355Error
+    sd = O.make_generator_state(5, num_blocks=1)
+    net = S.GeneratorRRDB(num_blocks=1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    x = torch.rand(1, 3, 512, 1280, generator=torch.Generator().manual_seed(6)).to(DEV)    # 32 x 40 tiles of 16 x 32
+    with torch.no_grad():
+        monkeypatch.setenv("SR355_CHAIN", "0")
+        ref = net(x).clone()
+        monkeypatch.delenv("SR355_CHAIN")
+        good = net(x).clone()
+        assert ops.chain_status(True) is True and torch.equal(good, ref)
+        try:
+            monkeypatch.setenv("SR355_CHAIN_GRID", "1280")
+            net(x)
+            with pytest.raises(Sr355Error, match="gave up"):
+                ops.chain_status(True)
+            assert ops.chain_status(True) is True                       # reported once
+            monkeypatch.delenv("SR355_CHAIN_GRID")
+            assert torch.equal(net(x), ref)                             # the device runs one launch per conv now
+            ops.chain_reenable()
+            monkeypatch.setenv("SR355_CHAIN_GRID", "1280")
+            net.checked = True
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                out = net(x)
+            assert torch.equal(out, ref) and any("repeated as one launch per conv" in str(w.message) for w in seen)
+        finally:
+            monkeypatch.delenv("SR355_CHAIN_GRID", raising=False)
+            net.checked = False
+            ops.chain_reenable()
+        assert torch.equal(net(x), ref) and ops.chain_status(True) is True
