@@ -1126,6 +1126,12 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         chain_collect = false;
         std::vector<ChainPass> passes;
         int prev_blocks = 0, prev_cout = 0;       // output-channel blocks (= passes) and channels of the conv before
+        // Stage order (ChainPass::perm).  A conv that appends to what the pass before it read walks the old stages in the
+        // reverse of that pass's order (the lines the L2 touched last come first) and the new channels last, where the
+        // wait for the neighbours sits; a second block of output channels walks the first block's order backwards.
+        const char *perm_env = getenv("SR355_CHAIN_PERM");      // 0: every pass in channel order (A/B measurements)
+        const bool permute = !perm_env || atoi(perm_env) != 0;
+        std::vector<int> prev_order;
         for (const ChainConv &cc : chain_convs) {
             const int S = cc.cin_units / 2;
             const int first_pass = (int)passes.size();
@@ -1134,6 +1140,30 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
                 memset(&ps, 0, sizeof(ps));
                 ps.a = cc.a;
                 ps.a.n_stages = ps.a.n_real_stages = S;
+                {
+                    std::vector<int> order;
+                    if (permute && S <= 16 && !cc.all_stages && (int)prev_order.size() <= S) {
+                        order.assign(prev_order.rbegin(), prev_order.rend());
+                        std::vector<bool> seen(S, false);
+                        bool ok = true;
+                        for (int v : order) {
+                            if (v >= S || seen[v]) ok = false;
+                            else seen[v] = true;
+                        }
+                        if (!ok) order.clear(), seen.assign(S, false);
+                        for (int v = 0; v < S; ++v)
+                            if (!seen[v]) order.push_back(v);
+                    } else {
+                        for (int v = 0; v < S; ++v) order.push_back(v);
+                    }
+                    if (S > 16) {
+                        set_error("generator forward: chain pass with %d stages (at most 16)", S);
+                        return SR355_ERR_UNSUPPORTED;
+                    }
+                    ps.perm = 0;
+                    for (int i = 0; i < 16; ++i) ps.perm |= (unsigned long long)(i < S ? order[i] : i) << (4 * i);
+                    prev_order = order;
+                }
                 ps.a.w = cc.a.w + (size_t)cb * 32 * 16;
                 ps.a.bias = cc.a.bias + cb * 32;
                 ps.cb_co = cb * 32;

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
     const int in_len = __builtin_amdgcn_readfirstlane(img_bytes);
     int it_ord = 0, it_stage = 0, it_S = 0, it_dep = 0, it_need = 0, it_dep2 = 0, it_need2 = 0, it_p = -1;
     int it_tx = 0, it_ty = 0, it_n = 0, it_i = -1;
+    unsigned it_perm_lo = 0x76543210u, it_perm_hi = 0xfedcba98u;   // stage order of the cursor's pass (ChainPass::perm)
 
     int cur_in_lo = 0, cur_in_hi = 0, cur_b_lo = 0, cur_b_hi = 0, cur_cout_pad = 32;
     // the 64-byte cursor record of pass P into LDS slot P & 1 (wave 0; lanes 16.. read beyond the range: zeros)
@@ -345,13 +346,15 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
         if (p_ != it_p) {                                                                             \
             /* the pass's cursor record, brought into the LDS when the cursor entered the pass before (landed: a   */ \
             /* stage boundary lies in between); then the request for the next pass's record                        */ \
-            chain_v4i r0_, r1_, r2_;                                                                  \
+            chain_v4i r0_, r1_, r2_, r3_;                                                             \
             const unsigned ra_ = (unsigned)(size_t)(smem + G::CUR_OFF + (p_ & 1) * 256);              \
-            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\t" \
-                         "s_waitcnt lgkmcnt(0)"                                                       \
-                         : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_)                                         \
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t" \
+                         "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"                      \
+                         : "=&v"(r0_), "=&v"(r1_), "=&v"(r2_), "=&v"(r3_)                             \
                          : "v"(ra_)                                                                   \
                          : "memory");                                                                 \
+            it_perm_lo = (unsigned)__builtin_amdgcn_readfirstlane(r3_[0]);                            \
+            it_perm_hi = (unsigned)__builtin_amdgcn_readfirstlane(r3_[1]);                            \
             w_lo = __builtin_amdgcn_readfirstlane(r0_[0]), w_hi = __builtin_amdgcn_readfirstlane(r0_[1]); \
             cur_in_lo = __builtin_amdgcn_readfirstlane(r0_[2]), cur_in_hi = __builtin_amdgcn_readfirstlane(r0_[3]); \
             cur_b_lo = __builtin_amdgcn_readfirstlane(r1_[0]), cur_b_hi = __builtin_amdgcn_readfirstlane(r1_[1]); \
@@ -415,8 +418,9 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
 #define SR355_ISSUE_DMA(SLOT, LIVE)                                                                   \
     {                                                                                                 \
         const bool live_ = (LIVE);                                                                    \
-        const int soff_in_ = __builtin_amdgcn_readfirstlane(it_stage * in_stage_stride);              \
-        const int soff_w_ = __builtin_amdgcn_readfirstlane(it_stage * w_stage_stride);                \
+        const int ps_ = (int)(((it_stage < 8 ? it_perm_lo : it_perm_hi) >> ((it_stage & 7) * 4)) & 15u); \
+        const int soff_in_ = __builtin_amdgcn_readfirstlane(ps_ * in_stage_stride);                   \
+        const int soff_w_ = __builtin_amdgcn_readfirstlane(ps_ * w_stage_stride);                     \
         const int dst0_ = (SLOT)*G::STAGE_BYTES + wave * 1024;                                        \
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                         \
             const int j = k * WAVES + wave;                                                           \

@@ -75,7 +75,8 @@ struct ChainCursor {
     unsigned long long w, in, bias;   // = a.w, a.in, a.bias
     int n_stages, cout_pad;           // = a.n_stages, a.cout_pad
     int need, dep_stage, need2, dep2_stage;
-    int pad[4];
+    unsigned perm_lo, perm_hi;        // = ChainPass::perm
+    int pad[2];
 };
 static_assert(sizeof(ChainCursor) == 64, "one dword per lane of a quarter-wave");
 struct ChainPass {
@@ -86,14 +87,19 @@ struct ChainPass {
     int dep_stage;    // first stage that reads the previous conv's output: n_stages = none, 0 = all, otherwise >= 2
     int need2;        // a second such point (a conv whose input was written by two passes: the first one's channels are
     int dep2_stage;   // needed from stage 0, the second one's from dep2_stage >= 2); need2 = 0: none
-    int pad[3];
+    // Order in which the pass walks its input-channel stages: nibble i = the stage requested i-th (at most 16 stages).
+    // A dense block's convs read the same leading channels one after the other; walking them in the reverse of the
+    // previous pass's order makes the first stages of a pass hit the lines the XCD's L2 touched last.
+    unsigned long long perm;
+    int pad[1];
 };
 inline void chain_fill_cursor(ChainPass &ps) {
     ps.cur.w = (unsigned long long)ps.a.w, ps.cur.in = (unsigned long long)ps.a.in;
     ps.cur.bias = (unsigned long long)ps.a.bias;
     ps.cur.n_stages = ps.a.n_stages, ps.cur.cout_pad = ps.a.cout_pad;
     ps.cur.need = ps.need, ps.cur.dep_stage = ps.dep_stage, ps.cur.need2 = ps.need2, ps.cur.dep2_stage = ps.dep2_stage;
-    ps.cur.pad[0] = ps.cur.pad[1] = ps.cur.pad[2] = ps.cur.pad[3] = 0;
+    ps.cur.perm_lo = (unsigned)ps.perm, ps.cur.perm_hi = (unsigned)(ps.perm >> 32);
+    ps.cur.pad[0] = ps.cur.pad[1] = 0;
 }
 // Rows a wave computes of the chain kernel's tile (tile = 4 waves x CHAIN_NB rows x 32 pixels) and the workgroups of
 // it a CU holds: 4 rows -> 62 KB of LDS, two per CU; 3 rows -> 51 KB, three per CU.

@@ -8,6 +8,8 @@ Tolerances
   an error; and a tight comparison against the oracle with bf16 storage rounding emulated.
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -386,9 +388,18 @@ def test_config2_size_properties():
         full = net(x.to(DEV))
         assert full.shape == (16, 3, 512, 512)
         assert torch.isfinite(full).all()
-        # samples are independent (no batch statistics): element 5 alone == element 5 of the batch
+        # samples are independent (no batch statistics): element 5 alone is element 5 of the batch.  The batch runs the
+        # body as one persistent launch whose passes walk the input channels in an L2-friendly order, a single patch
+        # runs one launch per conv in channel order: the same products in another fp32 summation order (bit-identical
+        # with SR355_CHAIN_PERM=0, tests/test_gpu_chain.py), so the two agree to bf16 rounding flips
         alone = net(x[5:6].to(DEV))
-        assert torch.equal(alone[0], full[5])
+        rms = (alone[0].double() - full[5].double()).pow(2).mean().sqrt().item()
+        assert rms < 5e-3 * full[5].double().std().item(), rms
+        os.environ["SR355_CHAIN_PERM"] = "0"
+        try:
+            assert torch.equal(net(x[5:6].to(DEV))[0], net(x.to(DEV))[5])
+        finally:
+            os.environ.pop("SR355_CHAIN_PERM", None)
         # determinism
         again = net(x.to(DEV))
         assert torch.equal(again, full)
