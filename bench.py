@@ -340,7 +340,7 @@ def _rate(fn, steps, warmup=2):
 def other_configs(net, dev, world, rank, dist):
     """The BASELINE configurations besides the headline one, as extras of the same JSON line:
     configs[0] (batch 4 of 64x64, the CPU case) on the GPU; configs[3] (a DIV2K-size 510x339 LR image -> 2040x1356)
-    whole, as four row bands with a 16-row halo on one GPU, and sharded by bands across the ranks with the final
+    whole, as four / eight tiles with halo on one GPU, and sharded one tile per rank with the final
     gather (N > 1); configs[4] (CycleGAN GeneratorSR and the conditional VAE on the same conv kernels)."""
     import super_resolution_amd as S
     out = {}
@@ -357,15 +357,22 @@ def other_configs(net, dev, world, rank, dist):
             whole = net(img)
             out["configs[3] 510x339 whole image on one GPU"] = {"value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s",
                                                                 "ms_per_image": round(sec * 1e3, 2)}
-            sec = _rate(lambda: S.tiled_forward(net, img, 4, 16), 5, 1)
-            tiled = S.tiled_forward(net, img, 4, 16)
-            out["configs[3] 510x339 as 4 row bands, halo 16, on one GPU"] = {
-                "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
-                "max_abs_vs_whole": float((tiled - whole).abs().max())}
+            from super_resolution_amd import sharded
+            for tiles in (4, 8):
+                g = sharded.best_grid(339, 510, tiles, sharded.DEFAULT_HALO)
+                wf = sharded.work_factor(339, 510, sharded.tile_edges(339, 510, g[0], g[1], sharded.DEFAULT_HALO))
+                sec = _rate(lambda: S.tiled_forward(net, img, tiles), 5, 1)
+                tiled = S.tiled_forward(net, img, tiles)
+                out[f"configs[3] 510x339 as {tiles} tiles ({g[0]} x {g[1]}, halo {sharded.DEFAULT_HALO}, one batch) on one GPU"] = {
+                    "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
+                    "work_factor": round(wf, 3), "max_abs_vs_whole": float((tiled - whole).abs().max())}
+            sec = _rate(lambda: S.tiled_forward(net, img, 8, halo=16, grid=(8, 1), batched=False), 3, 1)
+            out["configs[3] 510x339 as 8 row bands, halo 16, one after the other (round 2's cut)"] = {
+                "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2)}
             del whole, tiled
         if world > 1:
             def sharded():
-                return S.sharded_forward(net, img, halo=16)
+                return S.sharded_forward(net, img)
             for _ in range(2):
                 sharded()
             dist.barrier()
@@ -376,7 +383,7 @@ def other_configs(net, dev, world, rank, dist):
             dist.barrier()
             torch.cuda.synchronize()
             sec = _max_over_ranks((time.perf_counter() - t0) / 5, dev, dist)
-            out[f"configs[3] 510x339 sharded by row bands over {world} GPUs (halo 16, gather on rank 0)"] = {
+            out[f"configs[3] 510x339 sharded as one tile per rank over {world} GPUs (halo 8, gather on rank 0)"] = {
                 "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
                 "scaling": "strong"}
         if rank == 0:
@@ -507,6 +514,72 @@ def graphed_pixel_step(dev, lr, hr, steps):
         return {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
 
 
+def train_kernel_roofline(dev, batches=(16, 32, 64), size=32):
+    """The three kernels that make up four fifths of a training iteration, timed on their own at the training shape
+    (LR patches of 32x32) for several per-GPU batch sizes: the one-launch dense block (forward form, as the recorded
+    forward runs it), its data-gradient form (sign-gated by the saved activations) and the batched weight gradient of
+    a dense block's five convs.  Each is launched back to back through the C ABI between two HIP events on torch's
+    current stream (the stream the launches go to); FLOPs are 2*9*Cin*Cout per pixel and conv, the algorithmic bytes
+    what each kernel must read and write once per pixel (weights, 479 KB per block, not counted)."""
+    import super_resolution_amd as S
+    from super_resolution_amd import ops
+    nf, gc, units = 64, 32, 24
+    torch.manual_seed(0)
+    rdb = S.ResidualDenseBlock(nf, gc).to(dev)
+    packed = rdb._packed(S.DTYPE_BF16)
+    packs_t = rdb._packed_bwd()
+    zero = torch.zeros(64, dtype=torch.float32, device=dev)
+    flop_px = 2.0 * 9 * sum((nf + k * gc) * (gc if k < 4 else nf) for k in range(5))
+    bytes_px = {"dense_block_band (forward)": 2 * nf + 4 * nf + 4 * 2 * gc + 2 * nf + 4 * nf,
+                "dense_block_band_gated (data gradient)": 2 * nf + 4 * 2 * gc + 4 * 2 * gc + 4 * nf,
+                "wgrad3x3_kernel_mb1 (five convs) + reduction": 2 * 2 * (nf + 4 * gc)}
+    out = {"shape": f"LR patches of {size}x{size}, one dense block (64 + 4 x 32 channels)", "flop_per_pixel": flop_px,
+           "algorithmic_bytes_per_pixel": bytes_px, "peak_tflops": PEAK_BF16_TFLOPS, "peak_gbps": PEAK_HBM_GBPS,
+           "per_batch": {}}
+
+    def timed(launch, arg, reps=200):
+        for _ in range(10):
+            launch(arg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch(arg)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    for B in batches:
+        g = torch.Generator(device=dev).manual_seed(B)
+        buf = torch.randn((B, size, units, size, 8), generator=g, device=dev).to(torch.bfloat16)
+        nxt = torch.empty_like(buf)
+        stack = torch.randn((B, size, units, size, 8), generator=g, device=dev).to(torch.bfloat16)
+        trunk = torch.randn((B, size, nf // 4, size, 4), generator=g, device=dev)
+        dxc = torch.empty_like(trunk)
+        mask_off = [(nf + (3 - k) * gc) // 8 for k in range(4)]
+        fwd = ops.dense_block_args(buf, [w for w, _ in packed], [b for _, b in packed], 0.2, True, trunk, 0.2, None, 0.0,
+                                   nxt, trunk)
+        gated = ops.dense_block_args(stack, packs_t, [zero] * 5, 1.0, True, None, 1.0, None, 0.0, None, dxc, mask=buf,
+                                     mask_unit_off=mask_off, mask_slope=0.2)
+        dws = [torch.empty((gc if k < 4 else nf, nf + k * gc, 3, 3), dtype=torch.float32, device=dev) for k in range(5)]
+        dbs = [torch.empty((gc if k < 4 else nf,), dtype=torch.float32, device=dev) for k in range(5)]
+        need = ops._lib.lib().sr355_dense_block_wgrad_workspace_bytes(nf, gc, B, size, size)
+        wsb = torch.empty(need, dtype=torch.uint8, device=dev)
+        wg = ops.dense_wgrad_args(buf, stack, nf, gc, 1.0, 0.2, dws, dbs, wsb)
+        px = B * size * size
+        rows = {}
+        for name, launch, arg in (("dense_block_band (forward)", ops.launch_dense_block, fwd),
+                                  ("dense_block_band_gated (data gradient)", ops.launch_dense_block, gated),
+                                  ("wgrad3x3_kernel_mb1 (five convs) + reduction", ops.launch_dense_wgrad, wg)):
+            sec = timed(launch, arg)
+            rows[name] = {"avg_launch_us": round(sec * 1e6, 2), "tflops": round(flop_px * px / sec / 1e12, 1),
+                          "mfma_frac": round(flop_px * px / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
+                          "gbps": round(bytes_px[name] * px / sec / 1e9, 1),
+                          "hbm_frac": round(bytes_px[name] * px / sec / 1e9 / PEAK_HBM_GBPS, 4)}
+        out["per_batch"][str(B)] = rows
+    return out
+
+
 def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
     """Extra figures beside the headline, on 16 LR patches of 32x32 (128x128 HR) per GPU (BASELINE config 3 shapes):
     * the pixel pre-training iteration (esrgan/train.py:157-163: G forward, L1, backward, Adam);
@@ -549,6 +622,23 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
            "optimizer": opt_name}
     if world == 1 and graph:
         out["pixel_step_hipgraph"] = graphed_pixel_step(dev, lr, hr, steps)
+    if world == 1:
+        # per-GPU batch sweep (--batch_size is a flag of the reference, esrgan/train.py:20): where the step saturates
+        sweep = {}
+        for bsz in (32, 64):
+            try:
+                lr_b, hr_b = torch.rand(bsz, 3, 32, 32, device=dev), torch.rand(bsz, 3, 128, 128, device=dev)
+                el_b = _timed_steps(lambda: S.pixel_step(modelG, optG, lr_b, hr_b), dev, dist, steps, warmup)
+                sweep[str(bsz)] = {"value": round(bsz * steps / el_b, 1), "unit": "patches/s",
+                                   "ms_per_step": round(el_b / steps * 1e3, 2),
+                                   "generator_tflops": round(3 * FLOP_PER_LR_PIXEL * bsz * 32 * 32 * steps / el_b / 1e12, 1)}
+            except Exception as exc:
+                sweep[str(bsz)] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+        out["pixel_step_batch_sweep"] = sweep
+        try:
+            out["roofline"] = train_kernel_roofline(dev)
+        except Exception as exc:
+            out["roofline"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
     try:
         netD = S.Discriminator().to(dev).train()
         vgg = S.VGGFeatureExtractor(pretrained=False).to(dev)

@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 14
+#define SR355_ABI_VERSION 15
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -210,6 +210,28 @@ typedef struct sr355_wgrad_args {
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W);
 int sr355_conv3x3_wgrad(const sr355_wgrad_args *args, void *stream);
+
+/* The five weight / bias gradients of one dense block (autograd of /root/reference/esrgan/models/esrgan_model.py:18-24
+ * under loss.backward(), train.py:161, :220) as ONE batched launch plus one fixed-order reduction: `act` is the block's
+ * forward buffer [N][H][units][W][16 B] (x in channels [0, nf), the four growth outputs behind it), `stack` its
+ * gradient stack of the same geometry, [dOut (nf) | dY4 | dY3 | dY2 | dY1] (what the block's data-gradient pass
+ * leaves behind).  dw_dev[k] / db_dev[k] receive conv(k+1)'s gradients [cout][cin][3][3] / [cout] (overwritten), the
+ * growth convs' scaled by growth_scale, conv5's by conv5_scale (the dense skip's 0.2 times any outer factor).
+ * bf16, growth_channels <= 32, num_features <= 64, both multiples of 8.  The same kernels and summation order as five
+ * sr355_conv3x3_wgrad calls: the results are bit-identical. */
+typedef struct sr355_dense_wgrad_args {
+    int N, H, W;
+    const void *act_dev; size_t act_bytes;
+    const void *stack_dev; size_t stack_bytes;
+    int units;                 /* units per pixel of both buffers (>= (nf + 4 gc) / 8) */
+    int num_features, growth_channels;
+    float growth_scale, conv5_scale;
+    float *dw_dev[5];
+    float *db_dev[5];
+    void *workspace_dev; size_t workspace_bytes;
+} sr355_dense_wgrad_args;
+size_t sr355_dense_block_wgrad_workspace_bytes(int num_features, int growth_channels, int N, int H, int W);
+int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *args, void *stream);
 
 /* The same gradient on the exact-fp32 path (precision="fp32" modules under loss.backward(),
  * /root/reference/esrgan/train.py:161 with autocast off): `in` and `dy` are blocked fp32 tensors [N][H][units][W][4],

@@ -555,6 +555,42 @@ int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *p, void *stream) {
                            (hipStream_t)stream, p->dy_stride2);
 }
 
+size_t sr355_dense_block_wgrad_workspace_bytes(int num_features, int growth_channels, int N, int H, int W) {
+    if (N < 1 || H < 1 || W < 1 || cout_pad_for(growth_channels) != 32 || num_features < 8 || cout_pad_for(num_features) > 64 ||
+        ((num_features | growth_channels) & 7))
+        return 0;
+    return wgrad_block_workspace_bytes(num_features, growth_channels, N, H, W);
+}
+
+int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *p, void *stream) {
+    if (!p) {
+        set_error("dense_block_wgrad: args is null");
+        return SR355_ERR_INVALID;
+    }
+    const int nf = p->num_features, gc = p->growth_channels;
+    const size_t need = sr355_dense_block_wgrad_workspace_bytes(nf, gc, p->N, p->H, p->W);
+    if (!need) {
+        set_error("dense_block_wgrad: N=%d H=%d W=%d nf=%d gc=%d not supported (growth <= 32, features <= 64, multiples of 8)",
+                  p->N, p->H, p->W, nf, gc);
+        return SR355_ERR_UNSUPPORTED;
+    }
+    const size_t buf = (size_t)p->N * p->H * p->W * p->units * 16;
+    if (p->units * 8 < nf + 4 * gc || !p->act_dev || !p->stack_dev || !aligned16(p->act_dev) || !aligned16(p->stack_dev) ||
+        p->act_bytes < buf || p->stack_bytes < buf || !p->workspace_dev || !aligned16(p->workspace_dev) ||
+        p->workspace_bytes < need) {
+        set_error("dense_block_wgrad: buffers missing / too small (%d units for %d channels, %zu bytes each, %zu scratch bytes)",
+                  p->units, nf + 4 * gc, buf, need);
+        return SR355_ERR_INVALID;
+    }
+    for (int k = 0; k < 5; ++k)
+        if (!p->dw_dev[k] || !p->db_dev[k]) {
+            set_error("dense_block_wgrad: dw / db of conv%d missing", k + 1);
+            return SR355_ERR_INVALID;
+        }
+    return launch_wgrad3x3_block(p->act_dev, p->stack_dev, p->units, nf, gc, p->N, p->H, p->W, p->conv5_scale, p->dw_dev,
+                                 p->db_dev, (float *)p->workspace_dev, (hipStream_t)stream, nullptr, p->growth_scale);
+}
+
 size_t sr355_wgrad_f32_workspace_bytes(int cout, int cin, int N, int H, int W) {
     if (cout < 1 || cin < 1 || N < 1 || H < 1 || W < 1 || cout > 4096) return 0;
     return wgrad_f32_workspace_bytes(cout, cin, N, H, W);

@@ -643,12 +643,12 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
 // The five weight / bias gradients of one dense block (esrgan_model.py:18-24) in three launches: conv1..conv4
 // (growth convs, gc <= 32 outputs each, blockIdx.z = conv), conv5 (nf <= 64 outputs), one reduction.
 // `act` = the block's forward buffer, `stack` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
-// dw[k] / db[k] receive conv(k+1)'s gradients; conv5's is scaled by s5.
+// dw[k] / db[k] receive conv(k+1)'s gradients; conv5's is scaled by s5, the growth convs' by s_growth.
 // With `defer` (room for five jobs) the reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs
 // of several blocks, each of which then needs a slab area of its own until that launch.
 int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
                           float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
-                          WgradReduceJob *defer) {
+                          WgradReduceJob *defer, float s_growth) {
     if (cout_pad_for(gc) != 32 || cout_pad_for(nf) > 64 || ((nf | gc) & 7)) {
         set_error("wgrad3x3 block: nf=%d gc=%d not supported", nf, gc);
         return SR355_ERR_UNSUPPORTED;
@@ -671,7 +671,7 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
         wgrad_geometry(cin, N, H, W, &chunks, &G);
         const int dy_off = k < 4 ? (nf + (3 - k) * gc) / 8 : 0;   // stack order: dOut, dY4, dY3, dY2, dY1
         const size_t bias_off = off + (size_t)chunks * G * 9 * co_pad * 32;
-        rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[k], db[k], cout, cin, co_pad, G, k < 4 ? 1.f : s5};
+        rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[k], db[k], cout, cin, co_pad, G, k < 4 ? s_growth : s5};
         if (k < 4) {
             a.z_chunks[k] = chunks, a.z_groups[k] = G, a.z_dy_unit_off[k] = dy_off;
             a.z_co_off[k] = 0, a.z_co_stride[k] = co_pad;

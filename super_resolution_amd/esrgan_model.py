@@ -151,12 +151,18 @@ class ResidualDenseBlock(nn.Module):
             ops.conv3x3_fwd(stack, (nf + 4 * gc) // 8, packs[4], zero, nf, 1.0, 0, None, 0.0, None, 0.0, None, 0, dxc, None)
         if outer_scale != 1.0:          # the stack was built from the unscaled gradient: everything is linear in it
             dxc = dxc * outer_scale
-        for k, conv in enumerate(self._convs()):
-            cin, cout = nf + k * gc, (gc if k < 4 else nf)
-            dw = torch.empty_like(conv.weight, dtype=torch.float32)
-            db = torch.empty((cout,), dtype=torch.float32, device=dev)
-            dy_off = (nf + (3 - k) * gc) // 8 if k < 4 else 0
-            ops.conv3x3_wgrad(act, cin, 0, stack, dy_off, cout, outer_scale * (1.0 if k < 4 else self.res_scale), 0, dw, db)
+        convs = self._convs()
+        dws = [torch.empty_like(c.weight, dtype=torch.float32) for c in convs]
+        dbs = [torch.empty((gc if k < 4 else nf,), dtype=torch.float32, device=dev) for k in range(5)]
+        if gc <= 32 and nf <= 64 and not ((nf | gc) & 7):
+            # the five weight gradients as one batched launch + one reduction
+            ops.dense_block_wgrad_now(act, stack, nf, gc, outer_scale, outer_scale * self.res_scale, dws, dbs)
+        else:
+            for k in range(5):
+                dy_off = (nf + (3 - k) * gc) // 8 if k < 4 else 0
+                ops.conv3x3_wgrad(act, nf + k * gc, 0, stack, dy_off, gc if k < 4 else nf,
+                                  outer_scale * (1.0 if k < 4 else self.res_scale), 0, dws[k], dbs[k])
+        for dw, db in zip(dws, dbs):
             grads += [dw, db]
         return ops.from_blocked(dxc, 0, nf)
 

@@ -14,7 +14,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, DenseBlockArgs, GeneratorCfg, WgradArgs, check
+from ._lib import DTYPE_BF16, DTYPE_F32, ConvArgs, DenseBlockArgs, DenseWgradArgs, GeneratorCfg, WgradArgs, check
 
 _TORCH_DTYPE = {DTYPE_BF16: torch.bfloat16, DTYPE_F32: torch.float32}
 _CODE = {torch.bfloat16: DTYPE_BF16, torch.float32: DTYPE_F32}
@@ -224,14 +224,13 @@ def _(in_buf, cin_units, w_packed, bias_packed, cout, lrelu_slope, upsample, res
 DENSE_BLOCK_MAX_WIDTH = 32
 
 
-@torch.library.custom_op("sr355::dense_block_fwd", mutates_args=("buf", "out_act", "out_f32"))
-def dense_block_fwd(buf: Tensor, w_packed: List[Tensor], bias_packed: List[Tensor], lrelu_slope: float,
-                    store_growth: bool, res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor],
-                    res2_scale: float, out_act: Optional[Tensor], out_f32: Optional[Tensor],
-                    mask: Optional[Tensor] = None, mask_unit_off: Optional[List[int]] = None, mask_slope: float = 1.0,
-                    res1_weight: float = 1.0, res2_weight: float = 1.0, res_act: Optional[Tensor] = None) -> None:
-    """A whole dense block (conv1..conv4 + LeakyReLU appended to ``buf``, conv5 with the fused skip epilogue) in one
-    launch, for blocked bf16 buffers ``[N, H, 24, W <= 32, 8]``; bit-identical to five ``conv3x3_fwd`` calls."""
+def dense_block_args(buf: Tensor, w_packed: List[Tensor], bias_packed: List[Tensor], lrelu_slope: float,
+                     store_growth: bool, res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor],
+                     res2_scale: float, out_act: Optional[Tensor], out_f32: Optional[Tensor],
+                     mask: Optional[Tensor] = None, mask_unit_off: Optional[List[int]] = None, mask_slope: float = 1.0,
+                     res1_weight: float = 1.0, res2_weight: float = 1.0,
+                     res_act: Optional[Tensor] = None) -> DenseBlockArgs:
+    """The sr355_dense_block_args record of one fused dense-block launch (the tensors must outlive its use)."""
     _need_cuda(buf, res1, res2, out_act, out_f32, mask, res_act, *w_packed, *bias_packed)
     if buf.dtype != torch.bfloat16 or buf.dim() != 5 or buf.shape[2] != 24 or len(w_packed) != 5 or len(bias_packed) != 5:
         raise RuntimeError("dense_block_fwd: expected a blocked bf16 buffer [N, H, 24, W, 8] and five packed convs")
@@ -256,8 +255,31 @@ def dense_block_fwd(buf: Tensor, w_packed: List[Tensor], bias_packed: List[Tenso
     a.out_act_dev, a.out_act_bytes = _ptr(out_act), _nbytes(out_act)
     a.out_units = int(out_act.shape[2]) if out_act is not None else 0
     a.out_f32_dev = _ptr(out_f32)
+    return a
+
+
+def launch_dense_block(a: DenseBlockArgs) -> None:
+    """sr355_dense_block_fwd on the current device's current stream."""
+    check(_lib.lib().sr355_dense_block_fwd(C.byref(a), _stream()), "sr355_dense_block_fwd")
+
+
+def launch_dense_wgrad(a: DenseWgradArgs) -> None:
+    """sr355_dense_block_wgrad on the current device's current stream."""
+    check(_lib.lib().sr355_dense_block_wgrad(C.byref(a), _stream()), "sr355_dense_block_wgrad")
+
+
+@torch.library.custom_op("sr355::dense_block_fwd", mutates_args=("buf", "out_act", "out_f32"))
+def dense_block_fwd(buf: Tensor, w_packed: List[Tensor], bias_packed: List[Tensor], lrelu_slope: float,
+                    store_growth: bool, res1: Optional[Tensor], res1_scale: float, res2: Optional[Tensor],
+                    res2_scale: float, out_act: Optional[Tensor], out_f32: Optional[Tensor],
+                    mask: Optional[Tensor] = None, mask_unit_off: Optional[List[int]] = None, mask_slope: float = 1.0,
+                    res1_weight: float = 1.0, res2_weight: float = 1.0, res_act: Optional[Tensor] = None) -> None:
+    """A whole dense block (conv1..conv4 + LeakyReLU appended to ``buf``, conv5 with the fused skip epilogue) in one
+    launch, for blocked bf16 buffers ``[N, H, 24, W <= 32, 8]``; bit-identical to five ``conv3x3_fwd`` calls."""
+    a = dense_block_args(buf, w_packed, bias_packed, lrelu_slope, store_growth, res1, res1_scale, res2, res2_scale,
+                         out_act, out_f32, mask, mask_unit_off, mask_slope, res1_weight, res2_weight, res_act)
     with _on(buf.device):
-        check(_lib.lib().sr355_dense_block_fwd(C.byref(a), _stream()), "sr355_dense_block_fwd")
+        launch_dense_block(a)
 
 
 @dense_block_fwd.register_fake
@@ -360,6 +382,48 @@ def conv3x3_wgrad_f32(in_buf: Tensor, cin: int, upsample: int, dy: Tensor, dy_un
 
 @conv3x3_wgrad_f32.register_fake
 def _(in_buf, cin, upsample, dy, dy_unit_off, cout, scale, accumulate, dw, db):
+    return None
+
+
+def dense_wgrad_args(act: Tensor, stack: Tensor, nf: int, gc: int, growth_scale: float, conv5_scale: float,
+                     dw: List[Tensor], db: List[Tensor], workspace: Tensor) -> DenseWgradArgs:
+    """The sr355_dense_wgrad_args record of one batched dense-block weight-gradient launch."""
+    _need_cuda(act, stack, workspace, *dw, *db)
+    if act.dtype != torch.bfloat16 or stack.dtype != torch.bfloat16 or act.shape != stack.shape or act.dim() != 5:
+        raise RuntimeError("dense_block_wgrad: act and stack must be blocked bf16 buffers of one geometry")
+    if len(dw) != 5 or len(db) != 5 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in (*dw, *db)):
+        raise RuntimeError("dense_block_wgrad: five contiguous fp32 dw and db tensors")
+    a = DenseWgradArgs()
+    a.N, a.H, a.W, a.units = int(act.shape[0]), int(act.shape[1]), int(act.shape[3]), int(act.shape[2])
+    a.act_dev, a.act_bytes, a.stack_dev, a.stack_bytes = act.data_ptr(), _nbytes(act), stack.data_ptr(), _nbytes(stack)
+    a.num_features, a.growth_channels = int(nf), int(gc)
+    a.growth_scale, a.conv5_scale = float(growth_scale), float(conv5_scale)
+    for k in range(5):
+        cin, cout = nf + k * gc, (gc if k < 4 else nf)
+        if tuple(dw[k].shape) != (cout, cin, 3, 3) or db[k].numel() != cout:
+            raise RuntimeError(f"dense_block_wgrad: dw[{k}] / db[{k}] have the wrong shape")
+        a.dw_dev[k], a.db_dev[k] = dw[k].data_ptr(), db[k].data_ptr()
+    a.workspace_dev, a.workspace_bytes = workspace.data_ptr(), _nbytes(workspace)
+    return a
+
+
+@torch.library.custom_op("sr355::dense_block_wgrad", mutates_args=("dw", "db"))
+def dense_block_wgrad(act: Tensor, stack: Tensor, nf: int, gc: int, growth_scale: float, conv5_scale: float,
+                      dw: List[Tensor], db: List[Tensor]) -> None:
+    """Weight / bias gradients of the five convs of a dense block from its forward buffer and its gradient stack
+    ``[dOut | dY4 | dY3 | dY2 | dY1]``: one batched launch and one reduction, bit-identical to five ``conv3x3_wgrad``."""
+    L = _lib.lib()
+    need = L.sr355_dense_block_wgrad_workspace_bytes(int(nf), int(gc), int(act.shape[0]), int(act.shape[1]), int(act.shape[3]))
+    if need == 0:
+        raise RuntimeError("dense_block_wgrad: unsupported shape")
+    ws = torch.empty(need, dtype=torch.uint8, device=act.device)
+    a = dense_wgrad_args(act, stack, nf, gc, growth_scale, conv5_scale, dw, db, ws)
+    with _on(act.device):
+        check(L.sr355_dense_block_wgrad(C.byref(a), _stream()), "sr355_dense_block_wgrad")
+
+
+@dense_block_wgrad.register_fake
+def _(act, stack, nf, gc, growth_scale, conv5_scale, dw, db):
     return None
 
 
@@ -840,6 +904,7 @@ pixel_shuffle2_now = now(pixel_shuffle2)
 maxpool2x2_bwd_now = now(maxpool2x2_bwd)
 loss_fwd_now = now(loss_fwd)
 conv3x3_wgrad_now = now(conv3x3_wgrad)
+dense_block_wgrad_now = now(dense_block_wgrad)
 conv3x3_wgrad_f32_now = now(conv3x3_wgrad_f32)
 pack_weight_now = now(pack_weight)
 pack_weight_transposed_now = now(pack_weight_transposed)

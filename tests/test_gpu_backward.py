@@ -155,3 +155,27 @@ def test_weight_and_bias_gradient(case):
     ops.conv3x3_wgrad(xb, cin, ups, dyb, 3, cout, 0.5, 1, dw, db)
     torch.cuda.synchronize()
     assert (dw.cpu().double() - w0.grad).abs().max().item() < 2e-4 * max(1.0, scale_w)
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 32), (2, 9, 37), (1, 64, 96)])
+def test_dense_block_weight_gradients_in_one_launch_equal_five_launches(shape):
+    """sr355_dense_block_wgrad (the five weight / bias gradients of a dense block, autograd of
+    /root/reference/esrgan/models/esrgan_model.py:18-24, as one batched launch + one reduction) against five
+    sr355_conv3x3_wgrad calls on the same buffers: the same kernels and summation order, so bit-identical."""
+    N, H, W = shape
+    nf, gc, units = 64, 32, 24
+    act = torch.randn((N, H, units, W, 8), generator=torch.Generator().manual_seed(30)).to(DEV).to(torch.bfloat16)
+    stack = torch.randn((N, H, units, W, 8), generator=torch.Generator().manual_seed(31)).to(DEV).to(torch.bfloat16)
+    dws = [torch.full((gc if k < 4 else nf, nf + k * gc, 3, 3), 3.0, dtype=torch.float32, device=DEV) for k in range(5)]
+    dbs = [torch.full((gc if k < 4 else nf,), 3.0, dtype=torch.float32, device=DEV) for k in range(5)]
+    ops.dense_block_wgrad(act, stack, nf, gc, 0.7, 0.14, dws, dbs)
+    for k in range(5):
+        cin, cout = nf + k * gc, (gc if k < 4 else nf)
+        dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=DEV)
+        db = torch.empty((cout,), dtype=torch.float32, device=DEV)
+        dy_off = (nf + (3 - k) * gc) // 8 if k < 4 else 0
+        ops.conv3x3_wgrad(act, cin, 0, stack, dy_off, cout, 0.7 if k < 4 else 0.14, 0, dw, db)
+        torch.cuda.synchronize()
+        assert torch.equal(dw, dws[k]) and torch.equal(db, dbs[k]), k
+    with pytest.raises(RuntimeError):
+        ops.dense_block_wgrad(act, stack[:, :, :20].contiguous(), nf, gc, 1.0, 0.2, dws, dbs)

@@ -442,24 +442,69 @@ def test_hr_side_modes_clear_the_gate_with_margin():
 
 def test_config4_large_odd_image_full_and_banded():
     """BASELINE config 4: one 510x339 LR image (ragged against the 8x32 tiles on both axes) through the full
-    generator, against the oracle, and the same image as four row bands with a 16-row halo."""
-    from super_resolution_amd import tiled_forward
+    generator, against the oracle, and the same image as tiles with halo overlap (four and eight tiles, the grid
+    that computes the fewest pixels, all tiles as one batch; eight row bands one after the other)."""
+    from super_resolution_amd import sharded, tiled_forward
     sd = O.center_outputs(O.make_generator_state(0))
     net = load_net(S.GeneratorRRDB(), sd)
     x = torch.rand(1, 3, 339, 510, generator=torch.Generator().manual_seed(4321))
     with torch.no_grad():
         full = net(x.to(DEV))
         assert full.shape == (1, 3, 1356, 2040) and torch.isfinite(full).all()
-        banded = tiled_forward(net, x.to(DEV), bands=4, halo=16)
         ref = O.generator_forward(sd, x)
-    assert banded.shape == full.shape
-    out = full.cpu()
-    clamped, unclamped = O.psnr(out.clamp(0, 1), ref.clamp(0, 1)), O.psnr(out, ref)
-    seam = O.psnr(banded.cpu(), out)
-    print(f"config 4: PSNR vs fp32 oracle clamped {clamped:.2f} dB, unclamped {unclamped:.2f} dB; "
-          f"4 bands + halo 16 vs whole image {seam:.2f} dB")
+        out = full.cpu()
+        clamped, unclamped = O.psnr(out.clamp(0, 1), ref.clamp(0, 1)), O.psnr(out, ref)
+        print(f"config 4: PSNR vs fp32 oracle clamped {clamped:.2f} dB, unclamped {unclamped:.2f} dB")
+        assert clamped >= 50.0 and unclamped >= 50.0
+        for tiles, kw in ((4, {}), (8, {}), (8, {"grid": (8, 1), "batched": False, "halo": 16})):
+            got = tiled_forward(net, x.to(DEV), tiles, **kw)
+            assert got.shape == full.shape
+            seam = O.psnr(got.cpu(), out)
+            print(f"config 4: {tiles} tiles {kw or '(default grid, halo 8, one batch)'} vs whole image {seam:.2f} dB")
+            assert seam >= 50.0          # the halo approximation stays below the bf16 rounding level
+
+
+def test_config4_tiles_meet_the_fp32_bound():
+    """BASELINE config 4's gate as stated: in fp32, the tiled result is within 1e-3 (max-abs, outputs in [0, 1]) of
+    the whole-image forward (/root/reference/esrgan/test.py:71-72 runs the whole image in one call).  Four and eight
+    tiles with the default halo on the grid that computes the fewest pixels, and eight row bands; the work factor
+    (pixels computed over pixels of the image) of each cut is printed."""
+    from super_resolution_amd import sharded, tiled_forward
+    sd = O.center_outputs(O.make_generator_state(0))
+    net = load_net(S.GeneratorRRDB(precision="fp32"), sd)
+    x = torch.rand(1, 3, 339, 510, generator=torch.Generator().manual_seed(4321)).to(DEV)
+    with torch.no_grad():
+        whole = net(x)
+        inside = ((whole > 0) & (whole < 1)).float().mean().item()
+        for tiles, grid in ((4, None), (8, None), (8, (8, 1))):
+            g = grid or sharded.best_grid(339, 510, tiles, sharded.DEFAULT_HALO)
+            wf = sharded.work_factor(339, 510, sharded.tile_edges(339, 510, g[0], g[1], sharded.DEFAULT_HALO))
+            got = tiled_forward(net, x, tiles, grid=grid)
+            err = (got - whole).abs().max().item()
+            err_c = (got.clamp(0, 1) - whole.clamp(0, 1)).abs().max().item()
+            print(f"config 4 fp32: {tiles} tiles as {g[0]} x {g[1]}, halo {sharded.DEFAULT_HALO}: work factor {wf:.3f}, "
+                  f"max-abs vs whole image {err:.2e} (clamped {err_c:.2e}; {inside:.3f} of the outputs inside (0, 1))")
+            assert got.shape == whole.shape and err <= 1e-3
+        # halo 4 is not enough, which is why 8 is the default
+        assert (tiled_forward(net, x, 8, halo=2) - whole).abs().max().item() > 1e-3
+
+
+def test_config0_batch_of_four_64px_patches_against_the_oracle():
+    """BASELINE configs[0] (batch 4 of 3x64x64, the reference's CPU-runnable case) on the HIP path, both precisions,
+    against the oracle on the same weights and input."""
+    sd = O.center_outputs(O.make_generator_state(0))
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        ref = O.generator_forward(sd, x)
+        f32 = load_net(S.GeneratorRRDB(precision="fp32"), sd)(x.to(DEV)).cpu()
+        b16 = load_net(S.GeneratorRRDB(), sd)(x.to(DEV)).cpu()
+    err = (f32.clamp(0, 1) - ref.clamp(0, 1)).abs().max().item()
+    err_u = (f32 - ref).abs().max().item()
+    clamped, unclamped = O.psnr(b16.clamp(0, 1), ref.clamp(0, 1)), O.psnr(b16, ref)
+    print(f"configs[0]: fp32 max-abs {err:.2e} clamped / {err_u:.2e} unclamped; bf16 PSNR {clamped:.2f} dB clamped, "
+          f"{unclamped:.2f} dB unclamped; inside (0,1): {O.inside_unit_fraction(ref):.3f}")
+    assert f32.shape == (4, 3, 256, 256) and err <= 1e-3 and err_u <= 1e-3
     assert clamped >= 50.0 and unclamped >= 50.0
-    assert seam >= 50.0          # the halo approximation stays below the bf16 rounding level
 
 
 def test_fp16_hr_side_saturates_instead_of_overflowing():

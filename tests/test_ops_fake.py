@@ -15,7 +15,8 @@ N, H, W = 2, 9, 33
 OPS = ("to_blocked", "from_blocked", "pack_weight", "conv3x3_fwd", "pack_weight_transposed", "pool2x2_sum",
        "conv3x3_wgrad", "conv3x3_wgrad_f32", "generator_pack", "generator_forward", "generator_forward_u8", "generator_forward_train",
        "generator_pack_bwd", "generator_backward", "generator_backward_range", "adam_step", "dense_block_fwd",
-       "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd", "pixel_shuffle2")
+       "bn_lrelu_fwd", "bn_lrelu_bwd", "maxpool2x2_fwd", "maxpool2x2_bwd", "loss_fwd", "pixel_shuffle2",
+       "dense_block_wgrad")
 
 
 def test_every_op_is_registered_with_a_fake():
