@@ -264,8 +264,10 @@ int sr355_bn_lrelu_fwd(const float *x_f32_dev, size_t x_bytes, int N, int H, int
                        float *running_mean_dev, float *running_var_dev, long long *num_batches_tracked_dev,
                        float *save_mean_dev, float *save_rstd_dev, void *out_act_dev, size_t out_act_bytes,
                        int out_units, int out_unit_off, void *workspace_dev, size_t workspace_bytes, void *stream);
-/* Its backward pass (autograd of the same lines): dy_act = gradient of the output (blocked bf16); dx_act (blocked bf16,
- * the layout the conv's data / weight gradients read) = gradient of x; dgamma / dbeta [C] overwritten. */
+/* Its backward pass (autograd of the same lines): dy_act = gradient of the output (blocked bf16; or, with dy_units = 0
+ * and dy_unit_off = 0, an fp32 tensor [N][H][C/4][W][4]: what a data-gradient conv writes through out_f32_dev, so that
+ * the subtraction of the gradient's mean in here works on unrounded values); dx_act (blocked bf16, the layout the
+ * conv's data / weight gradients read) = gradient of x; dgamma / dbeta [C] overwritten. */
 int sr355_bn_lrelu_bwd(const float *x_f32_dev, size_t x_bytes, const void *dy_act_dev, size_t dy_bytes, int dy_units,
                        int dy_unit_off, int N, int H, int W, int C, const float *gamma_dev, const float *beta_dev,
                        const float *save_mean_dev, const float *save_rstd_dev, float lrelu_slope, int training,

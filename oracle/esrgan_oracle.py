@@ -108,8 +108,22 @@ def center_outputs(sd: StateDict, value: float = 0.5) -> StateDict:
 # --------------------------------------------------------------------------
 # forward
 # --------------------------------------------------------------------------
+class _RoundBf16(torch.autograd.Function):
+    """Round to bf16 in the forward pass, pass the gradient through unchanged.  (``t.to(bfloat16).to(float32)`` would
+    round the GRADIENT to bf16 as well on its way back through the casts: an emulation whose backward is meant to be
+    exact autograd must not, or a BatchNorm below amplifies the emulation's own rounding noise.)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def _bf16r(t: torch.Tensor) -> torch.Tensor:
-    return t.to(torch.bfloat16).to(torch.float32)
+    return _RoundBf16.apply(t) if t.requires_grad else t.to(torch.bfloat16).to(torch.float32)
 
 
 _HR_SIDE = ("upconv1", "upconv2", "HR_conv", "conv_last")
@@ -245,9 +259,14 @@ def discriminator_layout(base: int = 64) -> List[Tuple[int, int, int, int, Optio
 
 
 def discriminator_forward(sd: StateDict, img: torch.Tensor, training: bool, base: int = 64,
-                          momentum: float = 0.1, eps: float = 1e-5, emulate_bf16: bool = False) -> torch.Tensor:
+                          momentum: float = 0.1, eps: float = 1e-5, emulate_bf16: bool = False,
+                          slope_masks=None) -> torch.Tensor:
     """``emulate_bf16`` (not reference behaviour) rounds every conv's weights and input to bf16, the rounding
-    points of the HIP path (conv outputs feed BatchNorm in fp32 there)."""
+    points of the HIP path (conv outputs feed BatchNorm in fp32 there).  ``slope_masks`` (not reference behaviour
+    either; a test device): one boolean NCHW tensor per activation, True where the LeakyReLU passes its input
+    unchanged; the activation then multiplies by 1 / 0.2 as the mask says instead of looking at its own input's
+    sign.  With the masks of another forward pass of the same network this pins the piecewise-linear branch, so that
+    two backward passes can be compared without the slope flips that tiny forward differences cause."""
     x = img
     layout = discriminator_layout(base)
     for j, (ci, _cin, _cout, stride, bi) in enumerate(layout):
@@ -263,7 +282,10 @@ def discriminator_forward(sd: StateDict, img: torch.Tensor, training: bool, base
             x = F.batch_norm(x, sd[f"model.{bi}.running_mean"], sd[f"model.{bi}.running_var"],
                              sd[f"model.{bi}.weight"], sd[f"model.{bi}.bias"],
                              training=training, momentum=momentum, eps=eps)
-        x = F.leaky_relu(x, LRELU_SLOPE)
+        if slope_masks is not None:
+            x = x * torch.where(slope_masks[j], 1.0, LRELU_SLOPE)
+        else:
+            x = F.leaky_relu(x, LRELU_SLOPE)
     return x
 
 

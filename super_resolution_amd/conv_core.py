@@ -70,11 +70,12 @@ class _PackedWeights:
         self.key: Optional[Tuple] = None
         self.fwd: Optional[Tuple[Tensor, Tensor]] = None
         self.bwd: Optional[Tuple[Tensor, Tensor]] = None
+        self.bwd_split: Optional[Tuple[Tensor, Tensor]] = None
 
     def _sync(self, weight: Tensor, bias: Tensor) -> None:
         key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, weight.device)
         if key != self.key:
-            self.key, self.fwd, self.bwd = key, None, None
+            self.key, self.fwd, self.bwd, self.bwd_split = key, None, None, None
 
     def forward_pack(self, weight: Tensor, bias: Tensor) -> Tuple[Tensor, Tensor]:
         self._sync(weight, bias)
@@ -92,6 +93,26 @@ class _PackedWeights:
             ops.pack_weight_transposed(weight.detach(), 0, cin, 1.0, wt, units, 0, DTYPE_BF16)
             self.bwd = (wt, torch.zeros(_pad32(n_out), dtype=torch.float32, device=weight.device))
         return self.bwd
+
+
+    def backward_pack_split(self, weight: Tensor, bias: Tensor) -> Tuple[Tensor, Tensor]:
+        """The transposed pack for an output gradient carried as hi + lo bf16 pairs (channels [0, cout) the bf16
+        value, [cout, 2 cout) its rounding residue): every output channel's weights appear twice."""
+        self._sync(weight, bias)
+        if self.bwd_split is None:
+            cout, cin = weight.shape[0], weight.shape[1]
+            n_out = (cin + 3) // 4 * 4
+            units = units_for(2 * cout)
+            wt = torch.zeros(units * 9 * _pad32(n_out) * 16, dtype=torch.uint8, device=weight.device)
+            w2 = torch.cat([weight.detach(), weight.detach()], dim=0).contiguous()
+            ops.pack_weight_transposed(w2, 0, cin, 1.0, wt, units, 0, DTYPE_BF16)
+            self.bwd_split = (wt, torch.zeros(_pad32(n_out), dtype=torch.float32, device=weight.device))
+        return self.bwd_split
+
+
+def split_cotangent_fits(cout: int) -> bool:
+    """An NCHW output gradient of so few channels that value + rounding residue fit the units of the value alone."""
+    return 2 * cout <= units_for(cout) * 8
 
 
 def _packs_of(weight: Tensor) -> _PackedWeights:
@@ -139,23 +160,42 @@ def _conv_forward(x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kin
     return y
 
 
-def _conv_backward(x: Tensor, weight: Tensor, bias: Tensor, dyb: Tensor, stride: int, need_dx: bool, need_dw: bool):
+def _conv_backward(x: Tensor, weight: Tensor, bias: Tensor, dyb: Tensor, stride: int, need_dx: bool, need_dw: bool,
+                   dx_f32: bool = False, dy_split: bool = False):
     """Data / weight / bias gradients of one conv from the blocked bf16 gradient ``dyb`` of its (pre-activation)
-    output.  Stride 2: the data gradient reads ``dyb`` as its zero-inserted x2 image, the weight gradient likewise."""
+    output.  Stride 2: the data gradient reads ``dyb`` as its zero-inserted x2 image, the weight gradient likewise.
+    ``dx_f32``: the data gradient as an fp32 tensor ``[N, H, cin/4, W, 4]`` (cin a multiple of 16) instead of blocked
+    bf16 — for a consumer that subtracts means from it (a BatchNorm's backward).  ``dy_split``: ``dyb`` carries the
+    gradient as hi + lo bf16 pairs (``to_blocked(..., split=1)``: channels [cout, 2 cout) hold the rounding residue); the
+    data gradient multiplies both, the weight gradient reads the hi part."""
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     N, H, U, W, _ = x.shape
     dx = dw = db = None
     if need_dx:
-        wt, zero_bias = _packs_of(weight).backward_pack(weight, bias)
+        packs = _packs_of(weight)
+        wt, zero_bias = packs.backward_pack_split(weight, bias) if dy_split else packs.backward_pack(weight, bias)
+        if dy_split:
+            if stride != 1:
+                raise RuntimeError("conv3x3: a split output gradient is for stride-1 convs")
+            cout = 2 * cout          # (the data gradient's input channels)
         n_out = (cin + 3) // 4 * 4
-        alloc = torch.empty if U * 8 == n_out else torch.zeros
-        dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
-        if stride == 1:
-            ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, dx, 0, None, None)
+        if dx_f32:
+            if cin % 16:
+                raise RuntimeError("conv3x3: an fp32 data gradient needs a multiple of 16 input channels")
+            dx = torch.empty((N, H, cin // 4, W, 4), dtype=torch.float32, device=x.device)
+            out_act, out_f32 = None, dx
         else:
-            ops.launch_conv(ops.conv_args(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 1, None, 0.0, None, 0.0, dx, 0,
-                                          None, None, zero_insert=True))
+            alloc = torch.empty if U * 8 == n_out else torch.zeros
+            dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
+            out_act, out_f32 = dx, None
+        if stride == 1:
+            ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, out_act, 0,
+                                out_f32, None)
+        else:
+            ops.launch_conv(ops.conv_args(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 1, None, 0.0, None, 0.0, out_act,
+                                          0, out_f32, None, zero_insert=True))
     if need_dw:
+        cout = int(weight.shape[0])
         dw = torch.empty_like(weight, dtype=torch.float32)
         db = torch.empty((cout,), dtype=torch.float32, device=x.device)
         ops.conv3x3_wgrad_all(x, cin, dyb, cout, dw, db, stride=stride)   # 64 output channels a kernel call, looped inside
@@ -174,10 +214,14 @@ class _Conv3x3(torch.autograd.Function):
     def backward(ctx, dy: Tensor):
         x, weight, bias, y = ctx.saved_tensors
         cout = int(weight.shape[0])
+        dy_split = False
         if ctx.out_kind == "nchw":
             if ctx.slope != 1.0:
                 raise RuntimeError("conv3x3: an NCHW output carries no fused activation")
-            dyb = ops.to_blocked_now(dy.float().contiguous(), units_for(cout), DTYPE_BF16)
+            # few output channels (a network's last conv): the cotangent as hi + lo bf16 pairs, so that what the layers
+            # below subtract from each other is not its rounding noise
+            dy_split = ctx.stride == 1 and split_cotangent_fits(cout)
+            dyb = ops.to_blocked_now(dy.float().contiguous(), units_for(cout), DTYPE_BF16, 1 if dy_split else 0)
         elif ctx.out_kind == "f32":                 # [N,H,C/4,W,4] fp32 -> [N,H,C/8,W,8] bf16
             N, H, _q, W, _c = dy.shape
             dyb = dy.reshape(N, H, cout // 8, 2, W, 4).permute(0, 1, 2, 4, 3, 5).reshape(N, H, cout // 8, W, 8)
@@ -189,7 +233,7 @@ class _Conv3x3(torch.autograd.Function):
                 dyb = (torch.ops.aten.threshold_backward(dyb, y, 0.0) if ctx.slope == 0.0
                        else torch.ops.aten.leaky_relu_backward(dyb, y, ctx.slope, False))
         dx, dw, db = _conv_backward(x, weight, bias, dyb, ctx.stride, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+                                    ctx.needs_input_grad[1] or ctx.needs_input_grad[2], dy_split=dy_split)
         return dx, dw, db, None, None, None
 
 

@@ -679,10 +679,17 @@ int sr355_bn_lrelu_bwd(const float *x_f32, size_t x_bytes, const void *dy_act, s
                        const float *save_mean, const float *save_rstd, float lrelu_slope, int training, void *dx_act,
                        size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma, float *dbeta, void *workspace,
                        size_t workspace_bytes, void *stream) {
-    int rc = bn_checks("bn_lrelu_bwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd, dy_act, dy_bytes,
-                       dy_units, dy_unit_off, workspace, workspace_bytes);
+    // dy_units == 0: the gradient is an fp32 tensor in x's layout; the geometry check below then runs on dx's
+    const bool dy_f32 = dy_units == 0;
+    int rc = bn_checks("bn_lrelu_bwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd,
+                       dy_f32 ? dx_act : dy_act, dy_f32 ? dx_bytes : dy_bytes, dy_f32 ? dx_units : dy_units,
+                       dy_f32 ? dx_unit_off : dy_unit_off, workspace, workspace_bytes);
     if (rc) return rc;
     const size_t px = (size_t)N * H * W;
+    if (dy_f32 && (!dy_act || !aligned16(dy_act) || dy_unit_off != 0 || dy_bytes < px * C * 4)) {
+        set_error("bn_lrelu_bwd: fp32 gradient (dy_units = 0) missing, misaligned or smaller than %zu bytes", px * C * 4);
+        return SR355_ERR_INVALID;
+    }
     if (!dx_act || !aligned16(dx_act) || dx_unit_off < 0 || dx_unit_off + C / 8 > dx_units ||
         dx_bytes < px * dx_units * 16 || !dgamma || !dbeta) {
         set_error("bn_lrelu_bwd: dx geometry invalid or dgamma / dbeta missing");

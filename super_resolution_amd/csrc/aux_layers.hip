@@ -154,8 +154,30 @@ __global__ void bn_lrelu_apply_kernel(const float4 *__restrict__ x, size_t n_ite
     }
 }
 
+// The four gradient values of channel quad cq of one pixel: from a blocked bf16 tensor, or (DYF32) from an fp32 tensor
+// in the layout of x, [rows][Q][W][4] — what a data-gradient conv writes when its result feeds this backward pass
+// (rounding the gradient to bf16 first costs BatchNorm's backward most of its accuracy: it subtracts the gradient's
+// mean, and an adversarial loss's gradient is nearly constant over the map).
+template <bool DYF32>
+__device__ __forceinline__ void bn_load_dy4(const void *dy, size_t row, int dy_units, int dy_unit_off, int Q, int cq, int W,
+                                            int px, float (&g)[4]) {
+    if constexpr (DYF32) {
+        const float4 v = reinterpret_cast<const float4 *>(dy)[(row * Q + cq) * W + px];
+        g[0] = v.x, g[1] = v.y, g[2] = v.z, g[3] = v.w;
+    } else {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __bf16 *>(dy) +
+                                                           ((row * dy_units + dy_unit_off + (cq >> 1)) * W + px) * 8 +
+                                                           (cq & 1) * 4);
+        __bf16 gv[4];
+        __builtin_memcpy(gv, &raw, 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (float)gv[j];
+    }
+}
+
 // Backward, pass 1: g = dy * lrelu'(z); per-workgroup sums of g and g * xhat for the four channels of a quad.
-__global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const __bf16 *__restrict__ dy, int dy_units,
+template <bool DYF32>
+__global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const void *__restrict__ dy, int dy_units,
                                       int dy_unit_off, int rows, int Q, int W, int parts, const float *__restrict__ mean,
                                       const float *__restrict__ rstd, const float *__restrict__ gamma,
                                       const float *__restrict__ beta, float slope, float *__restrict__ pg,
@@ -172,15 +194,13 @@ __global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const __bf16
         const size_t row = (size_t)(p + r * parts);
         const float4 xv = x[(row * Q + cq) * W + px];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        const uint2 raw = *reinterpret_cast<const uint2 *>(dy + ((row * dy_units + dy_unit_off + (cq >> 1)) * W + px) * 8 +
-                                                           (cq & 1) * 4);
-        __bf16 gv[4];
-        __builtin_memcpy(gv, &raw, 8);
+        float gv[4];
+        bn_load_dy4<DYF32>(dy, row, dy_units, dy_unit_off, Q, cq, W, px, gv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xs[j] - mu[j]) * rs[j];
             const float z = ga[j] * xh + be[j];
-            const float g = (float)gv[j] * (z > 0.f ? 1.f : slope);
+            const float g = gv[j] * (z > 0.f ? 1.f : slope);
             sg[j] += g, sx[j] += g * xh;
         }
     }
@@ -205,7 +225,8 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ pg, const float
 
 // Backward, pass 2: dx = gamma * rstd * (g - dbeta / m - xhat * dgamma / m) in training mode (the batch statistics
 // depend on x), gamma * rstd * g in eval mode; blocked bf16 out, the layout the conv's gradients read.
-__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const __bf16 *__restrict__ dy, int dy_units,
+template <bool DYF32>
+__global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const void *__restrict__ dy, int dy_units,
                                     int dy_unit_off, size_t n_items, int U, int W, const float *__restrict__ mean,
                                     const float *__restrict__ rstd, const float *__restrict__ gamma,
                                     const float *__restrict__ beta, const float *__restrict__ dbeta,
@@ -216,9 +237,15 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const __bf16 *
         const size_t t = i / W;
         const int u = (int)(t % U);
         const size_t row = t / U;
-        uint4 graw = reinterpret_cast<const uint4 *>(dy)[(row * dy_units + dy_unit_off + u) * W + px];
-        __bf16 gv[8], v[8];
-        __builtin_memcpy(gv, &graw, 16);
+        float gv[8];
+        __bf16 v[8];
+        {
+            float g0[4], g1[4];
+            bn_load_dy4<DYF32>(dy, row, dy_units, dy_unit_off, 2 * U, 2 * u, W, px, g0);
+            bn_load_dy4<DYF32>(dy, row, dy_units, dy_unit_off, 2 * U, 2 * u + 1, W, px, g1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = g0[j], gv[4 + j] = g1[j];
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const float4 xv = x[(row * (2 * U) + 2 * u + q) * W + px];
@@ -228,7 +255,7 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const __bf16 *
                 const int c = 8 * u + 4 * q + j;
                 const float xh = (xs[j] - mean[c]) * rstd[c];
                 const float z = gamma[c] * xh + beta[c];
-                float g = (float)gv[4 * q + j] * (z > 0.f ? 1.f : slope);
+                float g = gv[4 * q + j] * (z > 0.f ? 1.f : slope);
                 if (training) g = g - dbeta[c] * inv_m - xh * dgamma[c] * inv_m;
                 v[4 * q + j] = (__bf16)(gamma[c] * rstd[c] * g);
             }
@@ -399,14 +426,23 @@ int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_uni
     const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
     const float m = (float)((double)N * H * W);
     float *pg = workspace, *pgx = workspace + (size_t)parts * C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
-                       (const __bf16 *)dy, dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope,
-                       pg, pgx);
+    const bool dy_f32 = dy_units == 0;     // the gradient arrives as fp32 [N][H][C/4][W][4]
+    if (dy_f32)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, dy,
+                           dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope, pg, pgx);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, dy,
+                           dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope, pg, pgx);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pg, pgx, parts, C, dbeta, dgamma);
     const size_t n_items = (size_t)rows * U * W;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
-                       (const __bf16 *)dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta, dbeta,
-                       dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
+    if (dy_f32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream,
+                           (const float4 *)x, dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta,
+                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream,
+                           (const float4 *)x, dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta,
+                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
     return check_hip(hipGetLastError(), "bn_lrelu_bwd launch");
 }
 

@@ -21,6 +21,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import conv_core as cc
+from . import ops
+from ._lib import DTYPE_BF16
 
 
 def _need_cuda(x: Tensor, who: str) -> None:
@@ -57,8 +59,36 @@ class Discriminator(nn.Module):
             nn.Conv2d(b * 8, 1, 3, 1, 1),
         )
 
+    def _layers(self):
+        """(conv, bn or None, LeakyReLU slope or None) per conv of ``self.model``, in order; the last conv has neither."""
+        mods, out, i = list(self.model), [], 0
+        while i < len(mods):
+            conv = mods[i]
+            i += 1
+            bn = slope = None
+            if i < len(mods) and isinstance(mods[i], nn.BatchNorm2d):
+                bn = mods[i]
+                i += 1
+            if i < len(mods) and isinstance(mods[i], nn.LeakyReLU):
+                slope = float(mods[i].negative_slope)
+                i += 1
+            if not isinstance(conv, nn.Conv2d) or (bn is not None and slope is None):
+                raise RuntimeError("Discriminator: unexpected layer order in self.model")
+            out.append((conv, bn, slope))
+        if not out or out[-1][1] is not None or out[-1][2] is not None or any(sl is None for _c, _b, sl in out[:-1]):
+            raise RuntimeError("Discriminator: expected conv blocks with an activation and one final plain conv")
+        return out
+
     def forward(self, img: Tensor) -> Tensor:
         _need_cuda(img, "Discriminator")
+        params = [p for p in self.parameters()]
+        if torch.is_grad_enabled() and (img.requires_grad or any(p.requires_grad for p in params)):
+            # recorded: the whole network is one autograd node whose backward keeps the gradients between the layers
+            # in fp32 wherever a BatchNorm's backward consumes them
+            return _DiscriminatorFunction.apply(img, self, *params)
+        return self._forward_layers(img)
+
+    def _forward_layers(self, img: Tensor) -> Tensor:
         mods = list(self.model)
         x = cc.to_blocked(img)
         i = 0
@@ -78,6 +108,97 @@ class Discriminator(nn.Module):
                 i += 1
                 x = cc.conv3x3(x, conv.weight, conv.bias, act.negative_slope, stride=conv.stride[0])   # LeakyReLU fused
         raise RuntimeError("unreachable")
+
+
+class _DiscriminatorFunction(torch.autograd.Function):
+    """The discriminator (esrgan_model.py:64-87) as ONE autograd node: the forward runs the nine convs (stride 2 at the
+    output positions, fp32 into every BatchNorm) and the BatchNorm + LeakyReLU kernels on the blocked layout and keeps
+    what the backward needs; the backward (autograd of esrgan/train.py:205, :220) walks the layers in reverse and hands
+    the data gradient from layer to layer as an fp32 tensor wherever a BatchNorm's backward consumes it.  BatchNorm's
+    backward subtracts the gradient's mean over the batch and the map, and the adversarial losses' gradients are
+    nearly constant there: on bf16-rounded gradients the small remainder is mostly rounding noise (6-7 % error on every
+    parameter gradient with one autograd node per layer), on fp32 ones it is not."""
+
+    @staticmethod
+    def forward(ctx, img: Tensor, module: "Discriminator", *params: Tensor) -> Tensor:
+        layers = module._layers()
+        x = ops.to_blocked_now(img.detach().float().contiguous(), cc.units_for(img.shape[1]), DTYPE_BF16)
+        saved = []
+        out = None
+        for k, (conv, bn, slope) in enumerate(layers):
+            w, b, stride = conv.weight, conv.bias, int(conv.stride[0])
+            if k == len(layers) - 1:
+                out = cc._conv_forward(x, w, b, 1.0, "nchw", stride)
+                saved.append((x,))
+            elif bn is None:
+                y = cc._conv_forward(x, w, b, slope, "blocked", stride)
+                saved.append((x, y))
+                x = y
+            else:
+                cout = int(w.shape[0])
+                if cout % 16:
+                    raise RuntimeError("Discriminator: a normalised layer needs a multiple of 16 channels")
+                if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                    raise RuntimeError("Discriminator: BatchNorm2d with affine parameters, running statistics and a fixed "
+                                       "momentum")
+                y32 = cc._conv_forward(x, w, b, 1.0, "f32", stride)
+                N, H, _q, W, _c = y32.shape
+                mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+                rstd = torch.empty(cout, dtype=torch.float32, device=x.device)
+                act = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=x.device)
+                training = bool(bn.training)
+                ops.bn_lrelu_fwd_now(y32, bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(slope), training,
+                                     float(bn.momentum), bn.running_mean, bn.running_var, bn.num_batches_tracked, mean,
+                                     rstd, act, 0)
+                saved.append((x, y32, mean, rstd, training))
+                x = act
+        ctx.layers, ctx.saved, ctx.in_channels = layers, saved, int(img.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        layers, saved = ctx.layers, ctx.saved
+        need = ctx.needs_input_grad          # (img, module, *params)
+        grads = []                           # per layer, in reverse: its parameters' gradients in parameter order
+        g = None
+        p_at = 2 + sum(2 if bn is None else 4 for _c, bn, _s in layers)       # one past the last parameter
+        for k in range(len(layers) - 1, -1, -1):
+            conv, bn, slope = layers[k]
+            w, b, stride = conv.weight, conv.bias, int(conv.stride[0])
+            n_par = 2 if bn is None else 4
+            p_at -= n_par
+            need_dw = bool(need[p_at] or need[p_at + 1])
+            need_dx = k > 0 or bool(need[0])
+            dx_f32 = k > 0 and layers[k - 1][1] is not None        # the layer below ends in a BatchNorm
+            x = saved[k][0]
+            dgamma = dbeta = None
+            dy_split = False
+            if k == len(layers) - 1:
+                # the loss's gradient on the one-channel prediction map as hi + lo bf16 pairs: it is nearly constant
+                # over the map, the BatchNorm below removes the constant, and what is left must not be rounding noise
+                dy_split = stride == 1 and cc.split_cotangent_fits(int(w.shape[0]))
+                dyb = ops.to_blocked_now(dy.float().contiguous(), cc.units_for(int(w.shape[0])), DTYPE_BF16,
+                                         1 if dy_split else 0)
+            elif bn is None:
+                y = saved[k][1]
+                gb = g if g.dtype == torch.bfloat16 else cc._f32_layout_to_blocked(g)
+                dyb = (torch.ops.aten.threshold_backward(gb, y, 0.0) if slope == 0.0
+                       else torch.ops.aten.leaky_relu_backward(gb, y, slope, False))
+            else:
+                _x, y32, mean, rstd, training = saved[k]
+                cout = int(w.shape[0])
+                N, H, _q, W, _c = y32.shape
+                dyb = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=y32.device)
+                dgamma = torch.empty(cout, dtype=torch.float32, device=y32.device)
+                dbeta = torch.empty(cout, dtype=torch.float32, device=y32.device)
+                ops.bn_lrelu_bwd_now(y32, g.contiguous(), bn.weight.detach(), bn.bias.detach(), mean, rstd, float(slope),
+                                     training, dyb, dgamma, dbeta, 0, 0)
+            dx, dw, db = cc._conv_backward(x, w, b, dyb, stride, need_dx, need_dw, dx_f32=dx_f32, dy_split=dy_split)
+            grads.append([dw, db] if bn is None else [dw, db, dgamma, dbeta])
+            g = dx
+        d_img = ops.from_blocked_now(g.contiguous(), 0, ctx.in_channels) if need[0] else None
+        flat = [t for layer in reversed(grads) for t in layer]
+        return (d_img, None, *flat)
 
 
 _VGG19 = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")

@@ -495,15 +495,19 @@ def _(x_f32, gamma, beta, eps, slope, training, momentum, running_mean, running_
 def bn_lrelu_bwd(x_f32: Tensor, dy_act: Tensor, gamma: Tensor, beta: Tensor, save_mean: Tensor, save_rstd: Tensor,
                  slope: float, training: bool, dx_act: Tensor, dgamma: Tensor, dbeta: Tensor, dy_unit_off: int = 0,
                  dx_unit_off: int = 0) -> None:
-    """Backward of ``bn_lrelu_fwd``: the gradient of x as blocked bf16, and dgamma / dbeta."""
+    """Backward of ``bn_lrelu_fwd``: the gradient of x as blocked bf16, and dgamma / dbeta.  ``dy_act`` is the blocked
+    bf16 gradient of the output or an fp32 tensor ``[N, H, C/4, W, 4]`` (a data-gradient conv's ``out_f32``)."""
     _need_cuda(x_f32, dy_act, gamma, beta, save_mean, save_rstd, dx_act, dgamma, dbeta)
     N, H, Q, W, _c = (int(v) for v in x_f32.shape)
+    dy_f32 = dy_act.dtype == torch.float32
+    if dy_f32 and (tuple(dy_act.shape) != tuple(x_f32.shape) or dy_unit_off != 0 or not dy_act.is_contiguous()):
+        raise RuntimeError("bn_lrelu_bwd: an fp32 gradient must be a contiguous tensor of x's shape [N, H, C/4, W, 4]")
     L = _lib.lib()
     need = L.sr355_bn_workspace_bytes(N, H, W, 4 * Q)
     ws = torch.empty(need, dtype=torch.uint8, device=x_f32.device)
     with _on(x_f32.device):
         check(L.sr355_bn_lrelu_bwd(x_f32.data_ptr(), _nbytes(x_f32), dy_act.data_ptr(), _nbytes(dy_act),
-                                   int(dy_act.shape[2]), int(dy_unit_off), N, H, W, 4 * Q, gamma.data_ptr(),
+                                   0 if dy_f32 else int(dy_act.shape[2]), int(dy_unit_off), N, H, W, 4 * Q, gamma.data_ptr(),
                                    beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), float(slope),
                                    int(bool(training)), dx_act.data_ptr(), _nbytes(dx_act), int(dx_act.shape[2]),
                                    int(dx_unit_off), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), need, _stream()),

@@ -102,12 +102,17 @@ def test_two_block_reference_case_like_for_like(golden):
 
 def test_discriminator_gradients_like_for_like_away_from_initialisation():
     """A discriminator whose BatchNorm weights / biases / running buffers are perturbed (so that the normalisation's
-    backward is not the near-cancellation of an untrained net): every gradient <= 8 % against the oracle with bf16
-    conv operands (measured 5.9-7.0 %, the same on every tensor and on the input gradient, i.e. injected at the top
-    of the chain).  The MSE-GAN cotangent 2 (pred - 1) / n is nearly constant over the 4 x 4 prediction map, so the
-    gradient that reaches the last BatchNorm is nearly constant per channel and its backward, which subtracts the
-    batch mean and the projection on the normalised activations, removes most of it: the bf16 rounding of that
-    gradient (which the oracle's exact backward does not have) does not shrink with it."""
+    backward is not the near-cancellation of an untrained net), under the MSE-GAN loss, against autograd through the
+    oracle's forward with bf16 conv operands.
+
+    Two bf16 forward passes of one network (the HIP kernels', the emulation's) differ in their last bits, and wherever
+    a pre-activation lies within that distance of zero the two LeakyReLUs take different slopes: about 0.4 % of the
+    activations, each changing its gradient by a factor of five, which is 4-8 % in relative L2 on every gradient below
+    (tools/diag_dgrad2.py: the difference appears behind the top two BatchNorm layers, 64 and 256 samples per channel,
+    and nowhere else).  That is a property of comparing two rounded forwards, not of the backward pass: with the
+    slopes pinned to the HIP forward's (the oracle's activations multiply by 1 / 0.2 where the HIP path's did) every
+    gradient agrees within 2 % (measured 0.2-0.6 %); the unpinned comparison is kept with the bound that noise needs."""
+    from super_resolution_amd import conv_core as cc
     sd = O.make_discriminator_state(81)
     gen = torch.Generator().manual_seed(82)
     for k in list(sd):
@@ -119,28 +124,41 @@ def test_discriminator_gradients_like_for_like_away_from_initialisation():
     netD = S.Discriminator()
     netD.load_state_dict(sd)
     netD = netD.to(DEV).train()
-    xg = img.to(DEV).requires_grad_(True)
-    pred = netD(xg)
+    # the inputs of the convs = the activations in front of them: their signs are the slopes the HIP forward took
+    acts, plain = [], cc._conv_forward
+
+    def recording(x, *a, **k):
+        acts.append(x)
+        return plain(x, *a, **k)
+
+    cc._conv_forward = recording
+    try:
+        xg = img.to(DEV).requires_grad_(True)
+        pred = netD(xg)
+    finally:
+        cc._conv_forward = plain
     loss = torch.nn.functional.mse_loss(pred, torch.ones_like(pred))
     loss.backward()
-    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
-              for k, v in sd.items()}
-    xr = img.clone().requires_grad_(True)
-    pred_r = O.discriminator_forward(leaves, xr, True, emulate_bf16=True)
-    loss_r = torch.nn.functional.mse_loss(pred_r, torch.ones_like(pred_r))
-    loss_r.backward()
-    assert abs(loss.item() - loss_r.item()) < 2e-2 * abs(loss_r.item())
+    masks = [(cc.blocked_as_nchw(a).float().cpu() > 0) for a in acts[1:]]
     pre_bn = {f"model.{ci}.bias" for ci, _a, _b, _s, bi in O.discriminator_layout() if bi is not None}
-    errs = []
-    for k, p in netD.named_parameters():
-        if k in pre_bn:      # exactly zero in exact arithmetic (the normalisation removes a constant): noise on both sides
-            continue
-        errs.append((rel_l2(p.grad.cpu(), leaves[k].grad), k))
-    errs.sort(reverse=True)
-    print("discriminator like for like:", [(round(e, 4), k) for e, k in errs[:4]], " median", errs[len(errs) // 2][0],
-          " input", rel_l2(xg.grad.cpu(), xr.grad))
-    assert errs[0][0] < 8e-2, errs[0]
-    assert rel_l2(xg.grad.cpu(), xr.grad) < 8e-2
+    for pinned, bound in ((True, 2e-2), (False, 9e-2)):
+        leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                  for k, v in sd.items()}
+        xr = img.clone().requires_grad_(True)
+        pred_r = O.discriminator_forward(leaves, xr, True, emulate_bf16=True, slope_masks=masks if pinned else None)
+        loss_r = torch.nn.functional.mse_loss(pred_r, torch.ones_like(pred_r))
+        loss_r.backward()
+        assert abs(loss.item() - loss_r.item()) < 2e-2 * abs(loss_r.item())
+        errs = []
+        for k, p in netD.named_parameters():
+            if k in pre_bn:   # exactly zero in exact arithmetic (the normalisation removes a constant): noise on both sides
+                continue
+            errs.append((rel_l2(p.grad.cpu(), leaves[k].grad), k))
+        errs.sort(reverse=True)
+        e_in = rel_l2(xg.grad.cpu(), xr.grad)
+        print(f"discriminator like for like, slopes {'pinned to the HIP forward' if pinned else 'free'}:",
+              [(round(e, 4), k) for e, k in errs[:3]], " median", round(errs[len(errs) // 2][0], 4), " input", round(e_in, 4))
+        assert errs[0][0] < bound and e_in < bound, (pinned, errs[0], e_in)
 
 
 def _block_case(golden, name, module, specs):
