@@ -248,7 +248,9 @@ int sr355_conv3x3_wgrad_f32(const sr355_wgrad_args *args, void *stream);
  * that forbid allocation).  Shapes whose sr355_wgrad_workspace_bytes() exceeds SR355_STATIC_SCRATCH_BYTES are
  * rejected with SR355_ERR_INVALID.  All calls on one GPU share that GPU's array: calls that overlap in time on one
  * GPU (two streams, two threads) race; calls on one stream are ordered.  Results are bit-identical to
- * sr355_conv3x3_wgrad's. */
+ * sr355_conv3x3_wgrad's.  The FIRST call on a device also takes the array's address (hipGetSymbolAddress) and sets
+ * the kernel's shared-memory attribute: make one un-captured warm-up call per device before calling under stream
+ * capture. */
 #define SR355_STATIC_SCRATCH_BYTES (16u << 20)
 int sr355_conv3x3_wgrad_static(const sr355_wgrad_args *args, void *stream);
 

@@ -890,6 +890,13 @@ struct ChainOrder {
     hipEvent_t err_copied = nullptr;     // recorded behind the copy of the kernel's error word to the pinned host word
     bool err_recorded = false;
     std::atomic<bool> disabled{false};   // a launch gave up once: this device runs one launch per conv from then on
+    // pinned staging area of the pass table: the copy to the device is a true asynchronous copy, and the bytes it
+    // reads stay valid until `table_copied` says it is done (a copy from a local vector would have to be staged by the
+    // runtime before the call returns)
+    void *table_host = nullptr;
+    size_t table_cap = 0;
+    hipEvent_t table_copied = nullptr;
+    bool table_recorded = false;
 };
 static ChainOrder *chain_order(int dev) {
     static std::once_flag once[64];
@@ -897,7 +904,8 @@ static ChainOrder *chain_order(int dev) {
     if (dev < 0 || dev >= 64) return nullptr;
     std::call_once(once[dev], [dev] {
         if (hipEventCreateWithFlags(&ord[dev].done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ord[dev].err_copied, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&ord[dev].err_copied, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ord[dev].table_copied, hipEventDisableTiming) != hipSuccess)
             ord[dev].done = nullptr;
     });
     return ord[dev].done ? &ord[dev] : nullptr;
@@ -1240,10 +1248,31 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
         unsigned *err_host = chain_err_host(dev);
         if (chain_status_of(dev, false) == SR355_ERR_HIP) return SR355_ERR_HIP;   // (the device now runs one launch per conv)
-        if (check_hip(hipMemcpyAsync(fb.chain_table, passes.data(), passes.size() * sizeof(ChainPass),
-                                     hipMemcpyHostToDevice, stream), "hipMemcpyAsync") ||
-            check_hip(hipMemsetAsync(fb.chain_flags, 0, fb.chain_flag_bytes, stream), "hipMemsetAsync"))
+        ChainOrder *order = chain_order(dev);
+        if (!order) {
+            set_error("generator forward: cannot create the event that orders chain launches");
             return SR355_ERR_HIP;
+        }
+        {
+            std::lock_guard<std::mutex> lock(order->m);
+            const size_t bytes = passes.size() * sizeof(ChainPass);
+            if (order->table_recorded && check_hip(hipEventSynchronize(order->table_copied), "hipEventSynchronize"))
+                return SR355_ERR_HIP;      // (the previous forward's copy out of the staging area: long done)
+            if (order->table_cap < bytes) {
+                if (order->table_host) (void)hipHostFree(order->table_host);
+                order->table_host = nullptr, order->table_cap = 0;
+                if (check_hip(hipHostMalloc(&order->table_host, bytes, hipHostMallocDefault), "hipHostMalloc"))
+                    return SR355_ERR_HIP;
+                order->table_cap = bytes;
+            }
+            memcpy(order->table_host, passes.data(), bytes);
+            if (check_hip(hipMemcpyAsync(fb.chain_table, order->table_host, bytes, hipMemcpyHostToDevice, stream),
+                          "hipMemcpyAsync") ||
+                check_hip(hipEventRecord(order->table_copied, stream), "hipEventRecord") ||
+                check_hip(hipMemsetAsync(fb.chain_flags, 0, fb.chain_flag_bytes, stream), "hipMemsetAsync"))
+                return SR355_ERR_HIP;
+            order->table_recorded = true;
+        }
         ChainArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.passes = fb.chain_table;
@@ -1259,11 +1288,6 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             ca.trace = trace_dev;
         }
 #endif
-        ChainOrder *order = chain_order(dev);
-        if (!order) {
-            set_error("generator forward: cannot create the event that orders chain launches");
-            return SR355_ERR_HIP;
-        }
         ChainEvents *cev = g_chain_timing.load() ? chain_events(dev) : nullptr;
         {
             std::lock_guard<std::mutex> lock(order->m);

@@ -184,19 +184,25 @@ constexpr int WTH = 4;                     // tile rows
 constexpr int WPX = WTH * 32;              // 128 output pixels
 constexpr int WIPX = (WTH + 2) * 34;       // 204 haloed input pixels
 constexpr int W_OOB = 0x7fffff00;
+// In the LDS a unit (8 channels) of the output-gradient tile is DY_PITCH pixels apart, not WPX: 128 pixels x 16 bytes
+// is a multiple of the 256-byte bank row, and the four units a transposing read's half-wave touches would then sit on
+// the same banks (4-way conflicts: 43 % of this kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); 132 pixels shift each
+// unit by 16 banks.  (The input tile's unit pitch, 204 pixels, already does.)
+constexpr int DY_PITCH = WPX + 4;
 template <int MB>
 struct WGeo {
     static constexpr int CO = MB * 32;
     static constexpr int DY_ITEMS = MB * 4 * WPX;          // 512 * MB
-    static constexpr int DY_I = DY_ITEMS / 64;
+    static constexpr int DY_I = DY_ITEMS / 64;             // two DMA instructions per unit
     static constexpr int IN_ITEMS = 4 * WIPX;              // 816
     static constexpr int IN_I = (IN_ITEMS + 63) / 64;      // 13
     static constexpr int JTOT = DY_I + IN_I;
     static constexpr int KMAX = (JTOT + 2) / 3;
-    static constexpr int IN_OFF = DY_I * 1024;
-    static constexpr int STAGE_BYTES = JTOT * 1024;
+    static constexpr int IN_OFF = MB * 4 * DY_PITCH * 16;
+    static constexpr int STAGE_BYTES = IN_OFF + IN_I * 1024;
     static constexpr int N_STAGES = MB == 1 ? 3 : 2;       // tiles in LDS: one being multiplied, the others in flight
     static constexpr int LDS_BYTES = N_STAGES * STAGE_BYTES;
+    static_assert(WPX == 128, "a unit of the gradient tile is two 64-item DMA instructions");
 };
 }  // namespace
 
@@ -323,11 +329,13 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
             const int j = k * 3 + wave;                                                                 \
             if (j < G::JTOT) {                                                                          \
-                lds_void *l = (lds_void *)(dst + j * 1024);                                             \
-                if (j < G::DY_I)                                                                        \
+                if (j < G::DY_I) {                                                                      \
+                    lds_void *l = (lds_void *)(dst + ((j >> 1) * DY_PITCH + (j & 1) * 64) * 16);        \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, l, 16, voff[k], 0, 0, 0);         \
-                else                                                                                    \
+                } else {                                                                                \
+                    lds_void *l = (lds_void *)(dst + G::IN_OFF + (j - G::DY_I) * 1024);                 \
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l, 16, voff[k], 0, 0, 0);         \
+                }                                                                                       \
             }                                                                                           \
         }                                                                                               \
     }
@@ -357,7 +365,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     const int ch_half = g & 1, k_half = g >> 1;
     const int unit_in_block = 2 * ch_half + (p >> 1);          // of the 4 units of a 32-channel block
     const int byte_in_unit = (p & 1) * 8;
-    const int dy_lane = (unit_in_block * WPX + 8 * k_half + q) * 16 + byte_in_unit;
+    const int dy_lane = (unit_in_block * DY_PITCH + 8 * k_half + q) * 16 + byte_in_unit;
     const int in_lane = G::IN_OFF + (unit_in_block * WIPX + wave * 34 + 8 * k_half + q) * 16 + byte_in_unit;
 
     // Tiles blockIdx.x, + nwg, ...: a ring of N_STAGES slots, AHEAD tiles in flight behind the one being multiplied
@@ -397,7 +405,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
                 bf16x8 af[MB], bfr[3];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    af[mb] = read_tr_operand(buf + dy_lane + (mb * 4 * WPX + y * 32 + 16 * s) * 16);
+                    af[mb] = read_tr_operand(buf + dy_lane + (mb * 4 * DY_PITCH + y * 32 + 16 * s) * 16);
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {

@@ -50,6 +50,39 @@ def test_static_scratch_weight_gradient_matches_the_workspace_one_twice_in_a_row
         assert ref_dw.abs().max().item() > 0
 
 
+def test_static_scratch_call_allocates_no_device_memory():
+    """After one warm-up call on the device (the first call takes the array's address and sets the kernel's LDS
+    attribute), a call changes neither the driver's free memory nor torch's allocator counters: buffers are built
+    beforehand, the entry point is called directly."""
+    L = _lib.lib()
+    N, cin, cout, H, W = 16, 160, 32, 32, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, H, 20, W, 8), generator=g).to(torch.bfloat16).to(DEV)
+    dy = torch.randn((N, H, 4, W, 8), generator=g).to(torch.bfloat16).to(DEV)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=DEV)
+    db = torch.empty((cout,), dtype=torch.float32, device=DEV)
+    a = WgradArgs()
+    a.N, a.H, a.W, a.upsample = N, H, W, 0
+    a.in_dev, a.in_bytes, a.in_units, a.cin = x.data_ptr(), x.numel() * 2, 20, cin
+    a.dy_dev, a.dy_bytes, a.dy_units, a.dy_unit_off = dy.data_ptr(), dy.numel() * 2, 4, 0
+    a.cout, a.scale, a.accumulate = cout, 1.0, 0
+    a.dw_dev, a.dw_bytes, a.db_dev = dw.data_ptr(), dw.numel() * 4, db.data_ptr()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.sr355_conv3x3_wgrad_static(C.byref(a), stream), "warm-up")
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info()
+    stats0 = torch.cuda.memory_stats()
+    for _ in range(3):
+        _lib.check(L.sr355_conv3x3_wgrad_static(C.byref(a), stream), "sr355_conv3x3_wgrad_static")
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info()
+    stats1 = torch.cuda.memory_stats()
+    assert free1 == free0
+    for key in ("allocation.all.allocated", "segment.all.allocated", "allocated_bytes.all.current",
+                "reserved_bytes.all.current", "num_device_alloc"):
+        assert stats1.get(key) == stats0.get(key), key
+
+
 def test_static_scratch_rejects_shapes_beyond_its_size():
     L = _lib.lib()
     N, cin, cout, H, W = 64, 192, 64, 64, 64

@@ -15,6 +15,10 @@ import sys
 CUS, SIMDS = 256, 4
 
 
+# the conv kernels of the forward and the three kernels that make up most of a training iteration
+KERNELS = ("conv3x3", "dense_block_band", "wgrad3x3")
+
+
 def main():
     root = sys.argv[1]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
@@ -25,7 +29,7 @@ def main():
             a[1] += float(row["Counter_Value"])
     out = {}
     for name, ctr in acc.items():
-        if "conv3x3" not in name:
+        if not any(k in name for k in KERNELS):
             continue
         avg = {c: v[1] / v[0] for c, v in ctr.items()}
         n = max(v[0] for v in ctr.values())

@@ -25,12 +25,16 @@ def per_kernel(root, counter):
     return acc
 
 
+# the conv kernels of the forward and the three kernels that make up most of a training iteration
+KERNELS = ("conv3x3", "dense_block_band", "wgrad3x3")
+
+
 def main():
     root = sys.argv[1]
     fetch, write = per_kernel(root, "FETCH_SIZE"), per_kernel(root, "WRITE_SIZE")
     out = {}
     for name in fetch:
-        if "conv3x3" not in name:
+        if not any(k in name for k in KERNELS):
             continue
         n, f = fetch[name]
         nw, w = write.get(name, (0, 0.0))
