@@ -367,7 +367,7 @@ def other_configs(net, dev, world, rank, dist):
                     "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2),
                     "work_factor": round(wf, 3), "max_abs_vs_whole": float((tiled - whole).abs().max())}
             sec = _rate(lambda: S.tiled_forward(net, img, 8, halo=16, grid=(8, 1), batched=False), 3, 1)
-            out["configs[3] 510x339 as 8 row bands, halo 16, one after the other (round 2's cut)"] = {
+            out["configs[3] 510x339 as 8 row bands, halo 16, one after the other (row bands instead of a tile grid)"] = {
                 "value": round(hr_mpix / sec, 2), "unit": "HR Mpix/s", "ms_per_image": round(sec * 1e3, 2)}
             del whole, tiled
         if world > 1:

@@ -85,7 +85,7 @@ def test_bad_arguments_are_rejected_without_touching_a_device(L):
 
 
 def test_integration_snippet_quotes_the_header_constants():
-    """The ctypes stub in INTEGRATION.md is what a maintainer pastes: its ABI version, dtype code and config fields must
+    """The ctypes stub in the integration notes is what a maintainer pastes: its ABI version, dtype code and config fields must
     be the header's."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
