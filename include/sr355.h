@@ -356,10 +356,11 @@ float sr355_chain_last_ms(void);
 /* Health of that persistent launch (again without a counterpart in the reference, whose convs are separate launches,
  * esrgan_model.py:55-58).  Its workgroups wait for each other and must all be resident; where they cannot be (a
  * second process on the GPU, masked CUs) a wait gives up after two seconds, the forward's output is INVALID and the
- * kernel raises a word that the library copies back behind the launch.  sr355_chain_status(wait) answers for the most
- * recent such forward on the current device: SR355_OK, SR355_CHAIN_PENDING (wait == 0 only: the launch has not finished
- * yet) or, once per failed launch, SR355_ERR_HIP with the reason in sr355_last_error().  wait != 0 blocks until the
- * launch and the copy have completed: call it before consuming the output of a one-shot forward.  The next forward call
+ * kernel raises a word in pinned host memory that stays raised until it has been reported (a failed launch is not
+ * forgotten because later launches succeeded).  sr355_chain_status(wait) answers for the forwards issued so far on the
+ * current device: SR355_OK, SR355_CHAIN_PENDING (wait == 0 only: the most recent launch has not finished and none has
+ * failed yet) or, once per failure, SR355_ERR_HIP with the reason in sr355_last_error().  wait != 0 blocks until the
+ * most recent launch has completed: call it before consuming the output of a one-shot forward.  The next forward call
  * makes the same check without blocking.  After a failure the device runs the body as one launch per conv (slower,
  * no residency requirement) until sr355_chain_reenable(). */
 #define SR355_CHAIN_PENDING 1

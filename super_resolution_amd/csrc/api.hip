@@ -863,19 +863,27 @@ static bool use_dense_fused(const sr355_generator_cfg *cfg, int N, int H, int W)
     return (long long)N * ((H + 1) / 2) <= max_bands;
 }
 
-// The word the chain kernel raises when a wait gave up, copied back after every chain launch and looked at by the
-// next call: pinned host memory, one word per device.
-static unsigned *chain_err_host(int dev) {
+// The word the chain kernel raises when a wait gave up: pinned host memory mapped into the device's address space, one
+// word per device.  The kernel only ever stores 1 to it (a system-scope store, straight to the host word), the host
+// clears it when it reports the failure: a launch that gave up stays visible however many launches follow it before
+// anyone asks.
+static unsigned *chain_err_host(int dev, unsigned **device_view = nullptr) {
     static std::once_flag once[64];
     static unsigned *word[64] = {};
+    static unsigned *view[64] = {};
     if (dev < 0 || dev >= 64) return nullptr;
     std::call_once(once[dev], [dev] {
-        void *p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) {
-            *(volatile unsigned *)p = 0;
-            word[dev] = (unsigned *)p;
+        void *p = nullptr, *d = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return;
+        *(volatile unsigned *)p = 0;
+        if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) {
+            (void)hipHostFree(p);
+            return;
         }
+        word[dev] = (unsigned *)p;
+        view[dev] = (unsigned *)d;
     });
+    if (device_view) *device_view = view[dev];
     return word[dev];
 }
 
@@ -887,7 +895,7 @@ struct ChainOrder {
     std::mutex m;
     hipEvent_t done = nullptr;
     bool recorded = false;
-    hipEvent_t err_copied = nullptr;     // recorded behind the copy of the kernel's error word to the pinned host word
+    hipEvent_t err_copied = nullptr;     // recorded behind the chain launch: once it is done the error word is final for that launch
     bool err_recorded = false;
     std::atomic<bool> disabled{false};   // a launch gave up once: this device runs one launch per conv from then on
     // pinned staging area of the pass table: the copy to the device is a true asynchronous copy, and the bytes it
@@ -935,22 +943,21 @@ static int chain_status_of(int dev, bool wait) {
     unsigned *err_host = chain_err_host(dev);
     if (!order || !err_host) return SR355_OK;
     std::lock_guard<std::mutex> lock(order->m);
+    bool pending = false;
     if (order->err_recorded) {
         if (wait) {
             if (check_hip(hipEventSynchronize(order->err_copied), "hipEventSynchronize")) return SR355_ERR_HIP;
-        } else if (hipEventQuery(order->err_copied) != hipSuccess) {
-            return SR355_CHAIN_PENDING;
+        } else {
+            pending = hipEventQuery(order->err_copied) != hipSuccess;
         }
     }
-    if (*(volatile unsigned *)err_host) {
-        *(volatile unsigned *)err_host = 0;
-        order->disabled.store(true, std::memory_order_relaxed);
-        set_error("generator forward: the body's persistent launch gave up waiting for a workgroup that never became "
-                  "resident (is another process using this GPU?); that forward's output is invalid; this device now runs "
-                  "one launch per conv");
-        return SR355_ERR_HIP;
-    }
-    return SR355_OK;
+    if (!*(volatile unsigned *)err_host) return pending ? SR355_CHAIN_PENDING : SR355_OK;
+    *(volatile unsigned *)err_host = 0;
+    order->disabled.store(true, std::memory_order_relaxed);
+    set_error("generator forward: the body's persistent launch gave up waiting for a workgroup that never became "
+              "resident (is another process using this GPU?); that forward's output is invalid; this device now runs "
+              "one launch per conv");
+    return SR355_ERR_HIP;
 }
 
 // SR355_CHAIN_GRID=<n> (read on every call, tests only): launch the persistent kernel with exactly n workgroups even
@@ -1246,7 +1253,11 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         }
         int dev = 0;
         if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return SR355_ERR_HIP;
-        unsigned *err_host = chain_err_host(dev);
+        unsigned *err_dev = nullptr;
+        if (!chain_err_host(dev, &err_dev) || !err_dev) {
+            set_error("generator forward: cannot map the host word the persistent launch reports a failed wait in");
+            return SR355_ERR_HIP;
+        }
         if (chain_status_of(dev, false) == SR355_ERR_HIP) return SR355_ERR_HIP;   // (the device now runs one launch per conv)
         ChainOrder *order = chain_order(dev);
         if (!order) {
@@ -1278,7 +1289,7 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
         ca.passes = fb.chain_table;
         ca.n_passes = (int)passes.size();
         ca.flags = fb.chain_flags;
-        ca.err = fb.chain_flags + fb.chain_flag_bytes / 4 - 1;
+        ca.err = err_dev;
         ca.N = N, ca.H = H, ca.W = W, ca.in_units = ws.blk_units;
 #ifdef SR355_TRACE
         // timing builds: where wave 0 of every workgroup spent the launch (medians over the workgroups, microseconds)
@@ -1336,11 +1347,9 @@ static int run_forward(const sr355_generator_cfg *cfg, const std::vector<ConvSpe
             }
         }
 #endif
-        if (err_host) {
+        {
             std::lock_guard<std::mutex> lock(order->m);
-            if (check_hip(hipMemcpyAsync(err_host, ca.err, 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync") ||
-                check_hip(hipEventRecord(order->err_copied, stream), "hipEventRecord"))
-                return SR355_ERR_HIP;
+            if (check_hip(hipEventRecord(order->err_copied, stream), "hipEventRecord")) return SR355_ERR_HIP;
             order->err_recorded = true;
         }
     }

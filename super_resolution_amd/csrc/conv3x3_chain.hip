@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
             if (__all(!polls_ || v_ >= (unsigned)(NEED))) break;                                      \
             __builtin_amdgcn_s_sleep(2);                                                              \
             if (wall_clock64() - t0_ > 200000000ull) {   /* 2 s at 100 MHz: a peer is not resident */ \
-                if (lane == 0) __hip_atomic_store((gu32 *)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                if (lane == 0) __hip_atomic_store((gu32 *)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
                 gave_up = true;     /* no further waits in this workgroup: the output is invalid anyway */ \
             }                                                                                         \
         }                                                                                             \

@@ -86,8 +86,8 @@ def test_a_launch_that_gives_up_is_reported_on_the_same_call_path_and_retried(mo
     """The body's persistent launch needs every workgroup resident.  Forced to a grid that cannot be (one workgroup per
     tile of an image with more tiles than slots, so that resident tiles border tiles that are not: SR355_CHAIN_GRID),
     its waits give up after two seconds.  The status call
-    then reports that launch (once), the device falls back to one launch per conv, and a ``checked`` module returns the
-    valid result from the same call."""
+    then reports that launch (once, and also when good launches were queued behind it in the meantime), the device falls
+    back to one launch per conv, and a ``checked`` module returns the valid result from the same call."""
     import warnings
     from super_resolution_amd import ops
     from super_resolution_amd._lib import Sr355Error
@@ -111,6 +111,15 @@ def test_a_launch_that_gives_up_is_reported_on_the_same_call_path_and_retried(mo
             assert ops.chain_status(True) is True                       # reported once
             monkeypatch.delenv("SR355_CHAIN_GRID")
             assert torch.equal(net(x), ref)                             # the device runs one launch per conv now
+            ops.chain_reenable()
+            # a failure is not forgotten when good launches are queued behind it before anyone asks
+            monkeypatch.setenv("SR355_CHAIN_GRID", "1280")
+            net(x)
+            monkeypatch.delenv("SR355_CHAIN_GRID")
+            later = net(x)
+            with pytest.raises(Sr355Error, match="gave up"):
+                ops.chain_status(True)
+            assert torch.equal(later, ref) and ops.chain_status(True) is True
             ops.chain_reenable()
             monkeypatch.setenv("SR355_CHAIN_GRID", "1280")
             net.checked = True
