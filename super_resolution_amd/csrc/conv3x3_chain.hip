@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
             const int lo_ = is_in_ ? in_lo : w_lo, hi_ = is_in_ ? in_hi : w_hi;                       \
             const int len_ = is_in_ ? in_len : w_len, so_ = is_in_ ? soff_in_ : soff_w_;              \
             const int dst_ = exists_ ? dst0_ + k * WAVES * 1024 : G::DUMMY_OFF;                       \
-            const int vo_ = (live_ && exists_ && !SR355_EXP_NOLOAD_V) ? voff[k] : OOB;                \
+            const int vo_ = (live_ && exists_ && !SR355_EXP_NOLOAD_V) ? SR355_EXP_L2WRAP(voff[k], is_in_) : OOB;                \
             if (all_in_ && SR355_EXP_IN_AUX != 0)      /* (folds after unrolling) */                  \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(SR355_RSRC(lo_, hi_, len_), (lds_void *)(smem + dst_), 16,  \
                                                          vo_, so_, 0, SR355_EXP_IN_AUX);              \
@@ -495,6 +495,11 @@ __global__ __launch_bounds__(256, CHAIN_WG_PER_CU) void conv3x3_chain(const Chai
 #define SR355_EXP_NOLOAD_V true
 #else
 #define SR355_EXP_NOLOAD_V false
+#endif
+#ifdef SR355_EXP_L2LOAD   /* timing experiments only: every activation load wraps into the first 128 KB of its image (L2 hits) */
+#define SR355_EXP_L2WRAP(V, IS_IN) (((IS_IN) && (V) != OOB) ? ((V)&0x1fff0) : (V))
+#else
+#define SR355_EXP_L2WRAP(V, IS_IN) (V)
 #endif
 #ifdef SR355_EXP_SKIP2    /* timing experiments only: the second pass of a conv5 fetches no activations */
 #define SR355_EXP_SKIP2_V true
