@@ -1674,7 +1674,7 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
 
 // Backward workspace.
 struct BwdWs {
-    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, dfea, slabs, total;
+    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, GB3, dfea, slabs, total;
 };
 
 static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
@@ -1700,6 +1700,7 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     b.GB0 = take(P * ws.blk_units * 16);
     b.GB1 = take(P * ws.blk_units * 16);
     b.GB2 = take(P * ws.blk_units * 16);   // third gradient stack of the one-launch dense-block backward
+    b.GB3 = take(P * ws.blk_units * 16);   // fourth: an RRDB's three stacks stay whole until its weight gradients have been issued
     b.dfea = take(P * ws.nf_units * 16);
     size_t slab = 0;
     const int nf = c.num_features, gc = c.growth_channels;
@@ -1878,8 +1879,13 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // writes the next stack's units [0, nf) only after the weight gradients that read that stack are done).  One
     // launch per block: three, because the single launch also fills its own stack's growth units, which must not
     // be the stack the previous block's weight gradients are still reading.
-    const int n_gb = fused ? 3 : 2;
-    unsigned char *GB[3] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2};
+    // One-launch dense blocks with the weight gradients on the caller's stream: the weight gradients of an RRDB's three
+    // blocks go out as ONE launch behind the third block's data gradients (their workgroups keep every CU busy where one
+    // block's cannot); the three stacks then have to stay whole until that launch, hence a fourth buffer.
+    static const bool rrdb_knob = [] { const char *e = getenv("SR355_WGRAD_RRDB"); return !e || atoi(e) != 0; }();
+    const bool rrdb_wgrad = fused && !ss && rrdb_knob;
+    const int n_gb = rrdb_wgrad ? 4 : fused ? 3 : 2;
+    unsigned char *GB[4] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2, wb + bw.GB3};
     if (phase_begin == 0) {
     // grad_out -> blocked bf16
     if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
@@ -1920,6 +1926,9 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     int blocks_done = 0;   // dense blocks of this call whose wgrads have been issued
     WgradReduceJob pending[15];
     int n_pending = 0;
+    const void *rr_act[3] = {}, *rr_stack[3] = {};   // the blocks of the RRDB in hand, in the order of their data gradients
+    float rr_s5[3] = {};
+    float *rr_dw[3][5] = {}, *rr_db[3][5] = {};
     const size_t block_slab_floats = wgrad_block_workspace_bytes(nf, gc, N, H, W) / sizeof(float);
     for (int b = nb - 1; b >= 0; --b) {
         const int phase = nb - b;
@@ -1971,6 +1980,20 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                 for (int k = 0; k < 5; ++k) {
                     dw[k] = grads + goff[c1 + k];
                     db[k] = dw[k] + (size_t)specs[c1 + k].cout * specs[c1 + k].cin * 9;
+                }
+                if (rrdb_wgrad) {
+                    const int q = 2 - r;
+                    rr_act[q] = A, rr_stack[q] = GB[cur], rr_s5[q] = s5;
+                    for (int k = 0; k < 5; ++k) rr_dw[q][k] = dw[k], rr_db[q][k] = db[k];
+                    if (r == 0) {
+                        if ((rc = launch_wgrad3x3_blocks(3, rr_act, rr_stack, bu, nf, gc, N, H, W, rr_s5, rr_dw, rr_db, slabs,
+                                                         stream, pending)) ||
+                            (rc = launch_wgrad_reduce_jobs(pending, 15, nf, gc, stream)))
+                            return rc;
+                    }
+                    ++blocks_done;
+                    cur = nxt;
+                    continue;
                 }
                 if (ss && (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
                            check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))

@@ -154,7 +154,7 @@ __global__ void pool2x2_kernel(const T *__restrict__ in, int N, int H, int W, in
 // Weight gradient.  Workgroup = 3 waves; wave ky owns the three taps of kernel row ky.  Work item =
 // (4 x 32 pixel tile, chunk of 32 input channels); a workgroup sums its items in registers and
 // writes one slab [9][CO][32] at the end.
-constexpr int WGRAD_MAX_JOBS = 16;   // convs (or 32-output slices of one conv) a batched launch takes
+constexpr int WGRAD_MAX_JOBS = 18;   // convs (or 32-output slices of one conv) a batched launch takes: three dense blocks of six
 struct WgradArgs {
     const unsigned char *in;   // blocked bf16 activations (conv input)
     const unsigned char *dy;   // blocked bf16 gradient of the conv output
@@ -172,6 +172,7 @@ struct WgradArgs {
     int z_chunks[WGRAD_MAX_JOBS], z_groups[WGRAD_MAX_JOBS], z_dy_unit_off[WGRAD_MAX_JOBS];
     int z_co_off[WGRAD_MAX_JOBS], z_co_stride[WGRAD_MAX_JOBS];   // a job's 32 outputs sit at rows [co_off, co_off + 32) of slabs co_stride wide
     long long z_slab_off[WGRAD_MAX_JOBS], z_bias_off[WGRAD_MAX_JOBS];   // in floats from `slabs`; bias < 0: none
+    long long z_in_off[WGRAD_MAX_JOBS], z_dy_off[WGRAD_MAX_JOBS];       // in bytes from `in` / `dy`: jobs of several dense blocks
 };
 
 #ifdef SR355_EXP_WG_NOLOAD   /* timing experiment (wrong results): every tile load out of range, no memory traffic */
@@ -239,6 +240,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         nwg = a0.z_groups[z];
         if (chunk >= a0.z_chunks[z] || (int)blockIdx.x >= nwg) return;   // whole workgroup, before any barrier
         a.dy_unit_off = a0.z_dy_unit_off[z];
+        a.in += a0.z_in_off[z];
+        a.dy += a0.z_dy_off[z];
         a.bias_slabs = a0.z_bias_off[z] >= 0 ? a0.slabs + a0.z_bias_off[z] : nullptr;
         a.slabs = a0.slabs + a0.z_slab_off[z];
         co_off = a0.z_co_off[z];
@@ -648,23 +651,31 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
     return total;
 }
 
-// The five weight / bias gradients of one dense block (esrgan_model.py:18-24) in three launches: conv1..conv4
-// (growth convs, gc <= 32 outputs each, blockIdx.z = conv), conv5 (nf <= 64 outputs), one reduction.
-// `act` = the block's forward buffer, `stack` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
-// dw[k] / db[k] receive conv(k+1)'s gradients; conv5's is scaled by s5, the growth convs' by s_growth.
-// With `defer` (room for five jobs) the reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs
-// of several blocks, each of which then needs a slab area of its own until that launch.
-int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
-                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
-                          WgradReduceJob *defer, float s_growth) {
+// The five weight / bias gradients of each of n_blocks (1..3) dense blocks (esrgan_model.py:18-24) in ONE launch (blockIdx.z
+// = (block, conv): the growth convs, gc <= 32 outputs each, and conv5 as two jobs of 32 outputs) plus one reduction.
+// `act[b]` = block b's forward buffer, `stack[b]` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
+// dw[b][k] / db[b][k] receive conv(k+1)'s gradients; conv5's is scaled by s5[b], the growth convs' by s_growth.
+// Block b's slabs start at slabs + b * wgrad_block_workspace_bytes.  With `defer` (room for 5 * n_blocks jobs) the
+// reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs.
+// At training-patch sizes a block's launch is 416 workgroups of eight tiles on 256 CUs, bound by the latency of each
+// tile's fetch: three blocks in one launch keep every CU supplied with resident workgroups (measured 19 -> 14 us per
+// block at 16 patches of 32 x 32).
+int launch_wgrad3x3_blocks(int n_blocks, const void *const *act, const void *const *stack, int units, int nf, int gc,
+                           int N, int H, int W, const float *s5, float *const (*dw)[5], float *const (*db)[5],
+                           float *slabs, hipStream_t stream, WgradReduceJob *defer, float s_growth) {
     if (cout_pad_for(gc) != 32 || cout_pad_for(nf) > 64 || ((nf | gc) & 7)) {
         set_error("wgrad3x3 block: nf=%d gc=%d not supported", nf, gc);
         return SR355_ERR_UNSUPPORTED;
     }
+    const int n5 = cout_pad_for(nf) / 32, per_block = 4 + n5;
+    if (n_blocks < 1 || n_blocks * per_block > WGRAD_MAX_JOBS || n_blocks * 5 > WGRAD_MAX_JOBS) {
+        set_error("wgrad3x3 blocks: %d blocks exceed one launch", n_blocks);
+        return SR355_ERR_INVALID;
+    }
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = (const unsigned char *)act;
-    a.dy = (const unsigned char *)stack;
+    a.in = (const unsigned char *)act[0];
+    a.dy = (const unsigned char *)stack[0];
     a.slabs = slabs;
     a.N = N, a.H = H, a.W = W;
     a.in_units = units, a.ups = 0, a.dy_units = units;
@@ -673,45 +684,47 @@ int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf,
     WgradReduceTable rt;
     size_t off = 0;   // floats
     int max_chunks = 0, max_g = 0;
-    for (int k = 0; k < 5; ++k) {
-        const int cin = nf + k * gc, cout = k < 4 ? gc : nf, co_pad = cout_pad_for(cout);
-        int chunks, G;
-        wgrad_geometry(cin, N, H, W, &chunks, &G);
-        const int dy_off = k < 4 ? (nf + (3 - k) * gc) / 8 : 0;   // stack order: dOut, dY4, dY3, dY2, dY1
-        const size_t bias_off = off + (size_t)chunks * G * 9 * co_pad * 32;
-        rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[k], db[k], cout, cin, co_pad, G, k < 4 ? s_growth : s5};
-        if (k < 4) {
-            a.z_chunks[k] = chunks, a.z_groups[k] = G, a.z_dy_unit_off[k] = dy_off;
-            a.z_co_off[k] = 0, a.z_co_stride[k] = co_pad;
-            a.z_slab_off[k] = (long long)off, a.z_bias_off[k] = (long long)bias_off;
+    for (int b = 0; b < n_blocks; ++b) {
+        const long long in_off = (const unsigned char *)act[b] - a.in, dy_off = (const unsigned char *)stack[b] - a.dy;
+        for (int k = 0; k < 5; ++k) {
+            const int cin = nf + k * gc, cout = k < 4 ? gc : nf, co_pad = cout_pad_for(cout);
+            int chunks, G;
+            wgrad_geometry(cin, N, H, W, &chunks, &G);
+            const int dy_unit = k < 4 ? (nf + (3 - k) * gc) / 8 : 0;   // stack order: dOut, dY4, dY3, dY2, dY1
+            const size_t bias_off = off + (size_t)chunks * G * 9 * co_pad * 32;
+            rt.j[b * 5 + k] = WgradReduceJob{slabs + off, slabs + bias_off, dw[b][k], db[b][k], cout, cin, co_pad, G,
+                                             k < 4 ? s_growth : s5[b]};
+            // conv5 takes part as n5 jobs of 32 outputs each, written side by side into its slabs
+            for (int half = 0; half < (k < 4 ? 1 : n5); ++half) {
+                const int z = b * per_block + k + half;
+                a.z_chunks[z] = chunks, a.z_groups[z] = G, a.z_dy_unit_off[z] = dy_unit + half * 4;
+                a.z_co_off[z] = half * 32, a.z_co_stride[z] = co_pad;
+                a.z_slab_off[z] = (long long)off, a.z_bias_off[z] = (long long)bias_off;
+                a.z_in_off[z] = in_off, a.z_dy_off[z] = dy_off;
+            }
             if (chunks > max_chunks) max_chunks = chunks;
             if (G > max_g) max_g = G;
+            off += ((wgrad_workspace_bytes(cout, cin, N, H, W) + 255) & ~(size_t)255) / sizeof(float);
         }
-        off += ((wgrad_workspace_bytes(cout, cin, N, H, W) + 255) & ~(size_t)255) / sizeof(float);
     }
     int rc;
     if ((rc = wgrad_set_attr(0))) return rc;
-    // conv5 joins the launch as two more jobs of 32 outputs each, written side by side into its 64-wide slabs
-    const int n5 = cout_pad_for(nf) / 32;
-    for (int half = 0; half < n5; ++half) {
-        const int z = 4 + half;
-        int chunks, G;
-        wgrad_geometry(nf + 4 * gc, N, H, W, &chunks, &G);
-        a.z_chunks[z] = chunks, a.z_groups[z] = G, a.z_dy_unit_off[z] = half * 4;
-        a.z_co_off[z] = half * 32, a.z_co_stride[z] = cout_pad_for(nf);
-        a.z_slab_off[z] = (long long)(rt.j[4].slabs - slabs);
-        a.z_bias_off[z] = (long long)(rt.j[4].bias_slabs - slabs);
-        if (chunks > max_chunks) max_chunks = chunks;
-        if (G > max_g) max_g = G;
-    }
-    a.n_batch = 4 + n5;
-    hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, 4 + n5), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
+    a.n_batch = n_blocks * per_block;
+    hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(max_g, max_chunks, a.n_batch), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
     if (check_hip(hipGetLastError(), "wgrad3x3 block launch")) return SR355_ERR_HIP;
     if (defer) {
-        for (int k = 0; k < 5; ++k) defer[k] = rt.j[k];
+        for (int k = 0; k < 5 * n_blocks; ++k) defer[k] = rt.j[k];
         return SR355_OK;
     }
-    return launch_wgrad_reduce_jobs(rt.j, 5, nf, gc, stream);
+    return launch_wgrad_reduce_jobs(rt.j, 5 * n_blocks, nf, gc, stream);
+}
+
+int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
+                          float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
+                          WgradReduceJob *defer, float s_growth) {
+    float *dw1[1][5], *db1[1][5];
+    for (int k = 0; k < 5; ++k) dw1[0][k] = dw[k], db1[0][k] = db[k];
+    return launch_wgrad3x3_blocks(1, &act, &stack, units, nf, gc, N, H, W, &s5, dw1, db1, slabs, stream, defer, s_growth);
 }
 
 // One launch for the reductions of up to three dense blocks (blockIdx.y = job).

@@ -201,6 +201,9 @@ struct WgradReduceJob {
 int launch_wgrad3x3_block(const void *act, const void *stack, int units, int nf, int gc, int N, int H, int W, float s5,
                           float *const dw[5], float *const db[5], float *slabs, hipStream_t stream,
                           WgradReduceJob *defer = nullptr, float s_growth = 1.f);
+int launch_wgrad3x3_blocks(int n_blocks, const void *const *act, const void *const *stack, int units, int nf, int gc,
+                           int N, int H, int W, const float *s5, float *const (*dw)[5], float *const (*db)[5],
+                           float *slabs, hipStream_t stream, WgradReduceJob *defer = nullptr, float s_growth = 1.f);
 int launch_wgrad_reduce_jobs(const WgradReduceJob *jobs, int n, int nf, int gc, hipStream_t stream);
 int launch_wgrad3x3(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off, int N, int H,
                     int W, int cout, int cin, float scale, int accumulate, float *dw, float *db, float *slabs,
