@@ -176,9 +176,9 @@ int launch_pack_weight_table(const PackJob *jobs_host, int n, int dtype, void *t
                   "hipMemcpyAsync"))
         return SR355_ERR_HIP;
     if (dtype == SR355_DTYPE_BF16)
-        hipLaunchKernelGGL(pack_weight_table_kernel<__bf16>, dim3(48, n), dim3(256), 0, stream, (const PackJob *)table_dev);
+        hipLaunchKernelGGL(pack_weight_table_kernel<__bf16>, dim3(24, n), dim3(256), 0, stream, (const PackJob *)table_dev);
     else
-        hipLaunchKernelGGL(pack_weight_table_kernel<float>, dim3(48, n), dim3(256), 0, stream, (const PackJob *)table_dev);
+        hipLaunchKernelGGL(pack_weight_table_kernel<float>, dim3(24, n), dim3(256), 0, stream, (const PackJob *)table_dev);
     return check_hip(hipGetLastError(), "pack_weight table launch");
 }
 
