@@ -1674,7 +1674,7 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
 
 // Backward workspace.
 struct BwdWs {
-    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, GB3, dfea, slabs, total;
+    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, GBx[4], dfea, slabs, total;
 };
 
 static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
@@ -1700,7 +1700,10 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     b.GB0 = take(P * ws.blk_units * 16);
     b.GB1 = take(P * ws.blk_units * 16);
     b.GB2 = take(P * ws.blk_units * 16);   // third gradient stack of the one-launch dense-block backward
-    b.GB3 = take(P * ws.blk_units * 16);   // fourth: an RRDB's three stacks stay whole until its weight gradients have been issued
+    // four more where the dense blocks run as one launch each (narrow images): the stacks of two RRDBs' six blocks stay whole
+    // until their weight gradients have been issued as one launch
+    const bool narrow = use_dense_fused(&c, N, H, W);
+    for (int k = 0; k < 4; ++k) b.GBx[k] = take(narrow ? P * ws.blk_units * 16 : 0);
     b.dfea = take(P * ws.nf_units * 16);
     size_t slab = 0;
     const int nf = c.num_features, gc = c.growth_channels;
@@ -1717,6 +1720,7 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     // a dense block's five at once, and three blocks' worth: an RRDB's reductions run as one launch
     const size_t block_slabs = wgrad_block_workspace_bytes(nf, gc, N, H, W);
     if (3 * block_slabs > slab) slab = 3 * block_slabs;
+    if (narrow && 6 * block_slabs > slab) slab = 6 * block_slabs;
     b.slabs = take(slab);
     b.total = off;
     return b;
@@ -1882,10 +1886,12 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // One-launch dense blocks with the weight gradients on the caller's stream: the weight gradients of an RRDB's three
     // blocks go out as ONE launch behind the third block's data gradients (their workgroups keep every CU busy where one
     // block's cannot); the three stacks then have to stay whole until that launch, hence a fourth buffer.
-    static const bool rrdb_knob = [] { const char *e = getenv("SR355_WGRAD_RRDB"); return !e || atoi(e) != 0; }();
-    const bool rrdb_wgrad = fused && !ss && rrdb_knob;
-    const int n_gb = rrdb_wgrad ? 4 : fused ? 3 : 2;
-    unsigned char *GB[4] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2, wb + bw.GB3};
+    // SR355_WGRAD_RRDB = RRDBs per weight-gradient launch (0: one launch per dense block, 1, 2; default 2)
+    static const int rrdb_knob = [] { const char *e = getenv("SR355_WGRAD_RRDB"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : v > 2 ? 2 : v; }();
+    const bool rrdb_wgrad = fused && !ss && rrdb_knob > 0;
+    const int rr_max = 3 * rrdb_knob;              // dense blocks per weight-gradient launch
+    const int n_gb = rrdb_wgrad ? rr_max + 1 : fused ? 3 : 2;
+    unsigned char *GB[7] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2, wb + bw.GBx[0], wb + bw.GBx[1], wb + bw.GBx[2], wb + bw.GBx[3]};
     if (phase_begin == 0) {
     // grad_out -> blocked bf16
     if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
@@ -1924,11 +1930,19 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     }   // phase 0
     // RRDBs in reverse (:35-39, :18-24); the gradient-stack buffer alternates once per dense block
     int blocks_done = 0;   // dense blocks of this call whose wgrads have been issued
-    WgradReduceJob pending[15];
+    WgradReduceJob pending[30];
     int n_pending = 0;
-    const void *rr_act[3] = {}, *rr_stack[3] = {};   // the blocks of the RRDB in hand, in the order of their data gradients
-    float rr_s5[3] = {};
-    float *rr_dw[3][5] = {}, *rr_db[3][5] = {};
+    const void *rr_act[6] = {}, *rr_stack[6] = {};   // the blocks whose weight gradients wait for their launch, in the order of
+    float rr_s5[6] = {};                              // their data gradients
+    float *rr_dw[6][5] = {}, *rr_db[6][5] = {};
+    int rr_n = 0;
+    auto rr_flush = [&]() -> int {
+        if (rr_n == 0) return SR355_OK;
+        int rc_ = launch_wgrad3x3_blocks(rr_n, rr_act, rr_stack, bu, nf, gc, N, H, W, rr_s5, rr_dw, rr_db, slabs, stream, pending);
+        if (!rc_) rc_ = launch_wgrad_reduce_jobs(pending, 5 * rr_n, nf, gc, stream);
+        rr_n = 0;
+        return rc_;
+    };
     const size_t block_slab_floats = wgrad_block_workspace_bytes(nf, gc, N, H, W) / sizeof(float);
     for (int b = nb - 1; b >= 0; --b) {
         const int phase = nb - b;
@@ -1982,15 +1996,10 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                     db[k] = dw[k] + (size_t)specs[c1 + k].cout * specs[c1 + k].cin * 9;
                 }
                 if (rrdb_wgrad) {
-                    const int q = 2 - r;
+                    const int q = rr_n++;
                     rr_act[q] = A, rr_stack[q] = GB[cur], rr_s5[q] = s5;
                     for (int k = 0; k < 5; ++k) rr_dw[q][k] = dw[k], rr_db[q][k] = db[k];
-                    if (r == 0) {
-                        if ((rc = launch_wgrad3x3_blocks(3, rr_act, rr_stack, bu, nf, gc, N, H, W, rr_s5, rr_dw, rr_db, slabs,
-                                                         stream, pending)) ||
-                            (rc = launch_wgrad_reduce_jobs(pending, 15, nf, gc, stream)))
-                            return rc;
-                    }
+                    if (rr_n == rr_max && (rc = rr_flush())) return rc;
                     ++blocks_done;
                     cur = nxt;
                     continue;
@@ -2053,6 +2062,7 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
             cur = nxt;
         }
     }
+    if ((rc = rr_flush())) return rc;
     if (phase_end < nb + 2) {   // join: the gradients of these phases are complete in stream order
         if (side_mark(0) || side_await(0)) return SR355_ERR_HIP;
         return SR355_OK;

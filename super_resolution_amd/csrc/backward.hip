@@ -157,7 +157,7 @@ __global__ void pool2x2_kernel(const T *__restrict__ in, int N, int H, int W, in
 // Weight gradient.  Workgroup = 3 waves; wave ky owns the three taps of kernel row ky.  Work item =
 // (4 x 32 pixel tile, chunk of 32 input channels); a workgroup sums its items in registers and
 // writes one slab [9][CO][32] at the end.
-constexpr int WGRAD_MAX_JOBS = 18;   // convs (or 32-output slices of one conv) a batched launch takes: three dense blocks of six
+constexpr int WGRAD_MAX_JOBS = 36;   // convs (or 32-output slices of one conv) a batched launch takes: six dense blocks of six
 struct WgradArgs {
     const unsigned char *in;   // blocked bf16 activations (conv input)
     const unsigned char *dy;   // blocked bf16 gradient of the conv output
@@ -654,15 +654,16 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
     return total;
 }
 
-// The five weight / bias gradients of each of n_blocks (1..3) dense blocks (esrgan_model.py:18-24) in ONE launch (blockIdx.z
+// The five weight / bias gradients of each of n_blocks (1..6) dense blocks (esrgan_model.py:18-24) in ONE launch (blockIdx.z
 // = (block, conv): the growth convs, gc <= 32 outputs each, and conv5 as two jobs of 32 outputs) plus one reduction.
 // `act[b]` = block b's forward buffer, `stack[b]` = its gradient stack [dOut(nf) | dY4 | dY3 | dY2 | dY1];
 // dw[b][k] / db[b][k] receive conv(k+1)'s gradients; conv5's is scaled by s5[b], the growth convs' by s_growth.
 // Block b's slabs start at slabs + b * wgrad_block_workspace_bytes.  With `defer` (room for 5 * n_blocks jobs) the
 // reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs.
 // At training-patch sizes a block's launch is 416 workgroups of eight tiles on 256 CUs, bound by the latency of each
-// tile's fetch: three blocks in one launch keep every CU supplied with resident workgroups (measured 19 -> 14 us per
-// block at 16 patches of 32 x 32).
+// tile's fetch: several blocks in one launch keep every CU supplied with resident workgroups (measured 19 -> 14.7 us per
+// block with three blocks a launch at 16 patches of 32 x 32; six blocks are 2,496 workgroups = 4.9 rounds of the 512 the
+// chip holds, three are 2.4).
 int launch_wgrad3x3_blocks(int n_blocks, const void *const *act, const void *const *stack, int units, int nf, int gc,
                            int N, int H, int W, const float *s5, float *const (*dw)[5], float *const (*db)[5],
                            float *slabs, hipStream_t stream, WgradReduceJob *defer, float s_growth) {
