@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -34,7 +34,7 @@ EXPORTS = (
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
     "sr355_chain_timing", "sr355_chain_last_ms", "sr355_chain_status", "sr355_chain_reenable",
-    "sr355_dense_block_wgrad_workspace_bytes", "sr355_dense_block_wgrad",
+    "sr355_dense_block_wgrad_workspace_bytes", "sr355_dense_block_wgrad", "sr355_dense_blocks_wgrad",
     "sr355_generator_saved_bytes", "sr355_generator_train_workspace_bytes", "sr355_generator_forward_train",
     "sr355_generator_packed_bwd_bytes", "sr355_generator_pack_bwd", "sr355_generator_bwd_workspace_bytes",
     "sr355_generator_grads_floats", "sr355_generator_backward",
@@ -171,6 +171,7 @@ def lib() -> C.CDLL:
     L.sr355_dense_block_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
     L.sr355_dense_block_wgrad_workspace_bytes.restype = sz
     L.sr355_dense_block_wgrad.argtypes = [C.POINTER(DenseWgradArgs), vp]
+    L.sr355_dense_blocks_wgrad.argtypes = [C.POINTER(DenseWgradArgs), i, vp]
     L.sr355_wgrad_f32_workspace_bytes.argtypes = [i, i, i, i, i]
     L.sr355_wgrad_f32_workspace_bytes.restype = sz
     L.sr355_conv3x3_wgrad_f32.argtypes = [C.POINTER(WgradArgs), vp]

@@ -562,11 +562,12 @@ size_t sr355_dense_block_wgrad_workspace_bytes(int num_features, int growth_chan
     return wgrad_block_workspace_bytes(num_features, growth_channels, N, H, W);
 }
 
-int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *p, void *stream) {
-    if (!p) {
-        set_error("dense_block_wgrad: args is null");
+int sr355_dense_blocks_wgrad(const sr355_dense_wgrad_args *args, int n_blocks, void *stream) {
+    if (!args || n_blocks < 1 || n_blocks > SR355_DENSE_WGRAD_MAX_BLOCKS) {
+        set_error("dense_blocks_wgrad: args is null or n_blocks=%d outside [1, %d]", n_blocks, SR355_DENSE_WGRAD_MAX_BLOCKS);
         return SR355_ERR_INVALID;
     }
+    const sr355_dense_wgrad_args *p = args;
     const int nf = p->num_features, gc = p->growth_channels;
     const size_t need = sr355_dense_block_wgrad_workspace_bytes(nf, gc, p->N, p->H, p->W);
     if (!need) {
@@ -575,20 +576,46 @@ int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *p, void *stream) {
         return SR355_ERR_UNSUPPORTED;
     }
     const size_t buf = (size_t)p->N * p->H * p->W * p->units * 16;
-    if (p->units * 8 < nf + 4 * gc || !p->act_dev || !p->stack_dev || !aligned16(p->act_dev) || !aligned16(p->stack_dev) ||
-        p->act_bytes < buf || p->stack_bytes < buf || !p->workspace_dev || !aligned16(p->workspace_dev) ||
-        p->workspace_bytes < need) {
-        set_error("dense_block_wgrad: buffers missing / too small (%d units for %d channels, %zu bytes each, %zu scratch bytes)",
-                  p->units, nf + 4 * gc, buf, need);
+    if (p->units * 8 < nf + 4 * gc || !p->workspace_dev || !aligned16(p->workspace_dev) ||
+        p->workspace_bytes < need * (size_t)n_blocks) {
+        set_error("dense_block_wgrad: %d units for %d channels, or scratch missing / smaller than %d x %zu bytes", p->units,
+                  nf + 4 * gc, n_blocks, need);
         return SR355_ERR_INVALID;
     }
-    for (int k = 0; k < 5; ++k)
-        if (!p->dw_dev[k] || !p->db_dev[k]) {
-            set_error("dense_block_wgrad: dw / db of conv%d missing", k + 1);
+    const void *act[SR355_DENSE_WGRAD_MAX_BLOCKS], *stack[SR355_DENSE_WGRAD_MAX_BLOCKS];
+    float s5[SR355_DENSE_WGRAD_MAX_BLOCKS];
+    float *dw[SR355_DENSE_WGRAD_MAX_BLOCKS][5], *db[SR355_DENSE_WGRAD_MAX_BLOCKS][5];
+    for (int b = 0; b < n_blocks; ++b) {
+        const sr355_dense_wgrad_args *q = args + b;
+        if (q->N != p->N || q->H != p->H || q->W != p->W || q->units != p->units || q->num_features != nf ||
+            q->growth_channels != gc || q->growth_scale != p->growth_scale) {
+            set_error("dense_blocks_wgrad: block %d differs from block 0 in shape, units or growth scale", b);
             return SR355_ERR_INVALID;
         }
-    return launch_wgrad3x3_block(p->act_dev, p->stack_dev, p->units, nf, gc, p->N, p->H, p->W, p->conv5_scale, p->dw_dev,
-                                 p->db_dev, (float *)p->workspace_dev, (hipStream_t)stream, nullptr, p->growth_scale);
+        if (!q->act_dev || !q->stack_dev || !aligned16(q->act_dev) || !aligned16(q->stack_dev) || q->act_bytes < buf ||
+            q->stack_bytes < buf) {
+            set_error("dense_block_wgrad: buffers of block %d missing / smaller than %zu bytes", b, buf);
+            return SR355_ERR_INVALID;
+        }
+        for (int k = 0; k < 5; ++k) {
+            if (!q->dw_dev[k] || !q->db_dev[k]) {
+                set_error("dense_block_wgrad: dw / db of conv%d missing (block %d)", k + 1, b);
+                return SR355_ERR_INVALID;
+            }
+            dw[b][k] = q->dw_dev[k], db[b][k] = q->db_dev[k];
+        }
+        act[b] = q->act_dev, stack[b] = q->stack_dev, s5[b] = q->conv5_scale;
+    }
+    return launch_wgrad3x3_blocks(n_blocks, act, stack, p->units, nf, gc, p->N, p->H, p->W, s5, dw, db,
+                                  (float *)p->workspace_dev, (hipStream_t)stream, nullptr, p->growth_scale);
+}
+
+int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *p, void *stream) {
+    if (!p) {
+        set_error("dense_block_wgrad: args is null");
+        return SR355_ERR_INVALID;
+    }
+    return sr355_dense_blocks_wgrad(p, 1, stream);
 }
 
 size_t sr355_wgrad_f32_workspace_bytes(int cout, int cin, int N, int H, int W) {

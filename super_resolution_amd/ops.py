@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -266,6 +266,18 @@ def launch_dense_block(a: DenseBlockArgs) -> None:
 def launch_dense_wgrad(a: DenseWgradArgs) -> None:
     """sr355_dense_block_wgrad on the current device's current stream."""
     check(_lib.lib().sr355_dense_block_wgrad(C.byref(a), _stream()), "sr355_dense_block_wgrad")
+
+
+DENSE_WGRAD_MAX_BLOCKS = 6      # SR355_DENSE_WGRAD_MAX_BLOCKS of include/sr355.h
+
+
+def launch_dense_wgrad_blocks(blocks: Sequence[DenseWgradArgs]) -> None:
+    """sr355_dense_blocks_wgrad: the weight gradients of up to six dense blocks of one shape (an RRDB's, or two RRDBs')
+    as one launch and one reduction; ``blocks[0].workspace`` must hold ``len(blocks)`` times the one-block size."""
+    if not 1 <= len(blocks) <= DENSE_WGRAD_MAX_BLOCKS:
+        raise RuntimeError(f"dense_blocks_wgrad takes 1 to {DENSE_WGRAD_MAX_BLOCKS} blocks")
+    arr = (DenseWgradArgs * len(blocks))(*blocks)
+    check(_lib.lib().sr355_dense_blocks_wgrad(arr, len(blocks), _stream()), "sr355_dense_blocks_wgrad")
 
 
 @torch.library.custom_op("sr355::dense_block_fwd", mutates_args=("buf", "out_act", "out_f32"))

@@ -179,3 +179,50 @@ def test_dense_block_weight_gradients_in_one_launch_equal_five_launches(shape):
         assert torch.equal(dw, dws[k]) and torch.equal(db, dbs[k]), k
     with pytest.raises(RuntimeError):
         ops.dense_block_wgrad(act, stack[:, :, :20].contiguous(), nf, gc, 1.0, 0.2, dws, dbs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_blocks", [2, 3, 6])
+def test_several_dense_blocks_in_one_weight_gradient_launch_equal_single_launches(n_blocks):
+    """sr355_dense_blocks_wgrad: the weight gradients of the dense blocks of one or two RRDBs
+    (/root/reference/esrgan/models/esrgan_model.py:30-33) as one launch + one reduction, through the C ABI, against one
+    sr355_dense_block_wgrad call per block: every block keeps its own slabs and summation order, so bit-identical.  Seven
+    blocks, differing shapes and a scratch buffer of one block's size are refused."""
+    from super_resolution_amd import _lib
+    N, H, W, nf, gc, units = 16, 32, 32, 64, 32, 24
+    L = _lib.lib()
+    one = L.sr355_dense_block_wgrad_workspace_bytes(nf, gc, N, H, W)
+    ws = torch.empty(n_blocks * one, dtype=torch.uint8, device=DEV)
+    gen = torch.Generator().manual_seed(40 + n_blocks)
+    blocks, expect = [], []
+    keep = []
+    for b in range(n_blocks):
+        act = torch.randn((N, H, units, W, 8), generator=gen).to(DEV).to(torch.bfloat16)
+        stack = torch.randn((N, H, units, W, 8), generator=gen).to(DEV).to(torch.bfloat16)
+        dws = [torch.full((gc if k < 4 else nf, nf + k * gc, 3, 3), 5.0, dtype=torch.float32, device=DEV) for k in range(5)]
+        dbs = [torch.full((gc if k < 4 else nf,), 5.0, dtype=torch.float32, device=DEV) for k in range(5)]
+        s5 = 0.04 if b % 3 == 0 else 0.2
+        blocks.append(ops.dense_wgrad_args(act, stack, nf, gc, 0.7, s5, dws, dbs, ws))
+        rdw = [torch.empty_like(t) for t in dws]
+        rdb = [torch.empty_like(t) for t in dbs]
+        ops.dense_block_wgrad(act, stack, nf, gc, 0.7, s5, rdw, rdb)
+        expect.append((rdw, rdb))
+        keep.append((act, stack, dws, dbs))
+    ops.launch_dense_wgrad_blocks(blocks)
+    torch.cuda.synchronize()
+    for b in range(n_blocks):
+        for k in range(5):
+            assert torch.equal(keep[b][2][k], expect[b][0][k]) and torch.equal(keep[b][3][k], expect[b][1][k]), (b, k)
+    with pytest.raises(RuntimeError):
+        ops.launch_dense_wgrad_blocks(blocks * 7)
+    if n_blocks > 1:
+        small = torch.empty(one, dtype=torch.uint8, device=DEV)
+        bad = list(blocks)
+        bad[0] = ops.dense_wgrad_args(keep[0][0], keep[0][1], nf, gc, 0.7, 0.2, keep[0][2], keep[0][3], small)
+        with pytest.raises(_lib.Sr355Error, match="scratch"):
+            ops.launch_dense_wgrad_blocks(bad)
+        other = torch.zeros((N, H // 2, units, W, 8), dtype=torch.bfloat16, device=DEV)
+        bad = list(blocks)
+        bad[1] = ops.dense_wgrad_args(other, other.clone(), nf, gc, 0.7, 0.2, keep[1][2], keep[1][3], ws)
+        with pytest.raises(_lib.Sr355Error, match="differs"):
+            ops.launch_dense_wgrad_blocks(bad)
