@@ -13,7 +13,7 @@ reduction kernel each (``conv_core.l1_loss`` / ``mse_loss``).  No CPU path.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -264,6 +264,77 @@ class VGGFeatureExtractor(nn.Module):
         return cc.from_blocked(h, channels)
 
 
+    def _plan(self) -> list:
+        """The feature stack as (kind, module, relu) steps: "conv" with its fused ReLU flag, "pool"."""
+        mods = list(self.features)
+        plan, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
+            if isinstance(m, nn.Conv2d):
+                relu = i < len(mods) and isinstance(mods[i], nn.ReLU)
+                plan.append(("conv", m, relu))
+                if relu:
+                    i += 1
+            elif isinstance(m, nn.MaxPool2d):
+                plan.append(("pool", m, False))
+            else:
+                raise RuntimeError(f"unexpected layer {type(m).__name__} in the VGG feature stack")
+        return plan
+
+    def forward_pair(self, sr: Tensor, hr: Tensor) -> Tuple[Tensor, Tensor]:
+        """``(self(sr), self(hr).detach())`` — the two calls of the perceptual term (train.py:214-216) — as ONE forward
+        over the concatenated batch: the extractor has no batch statistics, so every image's features are what the
+        separate calls give, the launches are half as many and twice as full (the deep layers see 8 x 8 pixel maps);
+        the backward runs the data gradients of the ``sr`` half only."""
+        _need_cuda(sr, "VGGFeatureExtractor")
+        if sr.shape != hr.shape or sr.device != hr.device:
+            raise RuntimeError("VGGFeatureExtractor.forward_pair: two batches of one shape on one device")
+        return _VGGPairFunction.apply(sr, hr, self)
+
+
+class _VGGPairFunction(torch.autograd.Function):
+    """The frozen VGG19 feature stack (esrgan_model.py:90-103) on ``cat(sr, hr)`` as one autograd node: the forward keeps,
+    for the ``sr`` half, each conv's input (and output where a ReLU is fused) and each pool's input; the backward walks
+    the layers in reverse for that half only (ReLU gate, data gradient of the conv, first-maximum pooling gradient).
+    The ``hr`` half of the result is marked non-differentiable (train.py:216 detaches it)."""
+
+    @staticmethod
+    def forward(ctx, sr: Tensor, hr: Tensor, module: "VGGFeatureExtractor"):
+        n = int(sr.shape[0])
+        x = torch.cat([sr.detach().float(), hr.detach().float()], dim=0).contiguous()
+        h = ops.to_blocked_now(x, cc.units_for(x.shape[1]), DTYPE_BF16)
+        saved, channels = [], int(x.shape[1])
+        for kind, m, relu in module._plan():
+            if kind == "conv":
+                y = cc._conv_forward(h, m.weight, m.bias, 0.0 if relu else 1.0, "blocked", 1)
+                saved.append(("conv", m, h[:n], y[:n] if relu else None))
+                h, channels = y, m.out_channels
+            else:
+                saved.append(("pool", m, h[:n], None))
+                h = ops.maxpool2x2_fwd_now(h)
+        out = ops.from_blocked_now(h, 0, channels)
+        ctx.saved, ctx.in_channels, ctx.units = saved, int(x.shape[1]), int(h.shape[2])
+        f_sr, f_hr = out[:n], out[n:]
+        ctx.mark_non_differentiable(f_hr)
+        return f_sr, f_hr
+
+    @staticmethod
+    def backward(ctx, g_sr: Tensor, _g_hr):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        g = ops.to_blocked_now(g_sr.float().contiguous(), ctx.units, DTYPE_BF16)
+        for k in range(len(ctx.saved) - 1, -1, -1):
+            kind, m, x, y = ctx.saved[k]
+            if kind == "pool":
+                g = ops.maxpool2x2_bwd_now(x.contiguous(), g.contiguous())
+                continue
+            if y is not None:
+                g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+            g, _dw, _db = cc._conv_backward(x.contiguous(), m.weight, m.bias, g.contiguous(), 1, True, False)
+        return ops.from_blocked_now(g.contiguous(), 0, ctx.in_channels), None, None
+
+
 # ------------------------------------------------------------------------------------------------
 def _backward_and_step(loss: Tensor, optimizer, scaler) -> None:
     if scaler is None:
@@ -284,6 +355,14 @@ def pixel_step(netG: nn.Module, optim_G, lr: Tensor, hr: Tensor, scaler=None) ->
     return {"loss_pix": loss_pix.detach()}
 
 
+def _perceptual_features(vgg: nn.Module, fake: Tensor, hr: Tensor) -> Tuple[Tensor, Tensor]:
+    """vgg(fake), vgg(hr) (train.py:214-216); one batched forward where the extractor offers it."""
+    pair = getattr(vgg, "forward_pair", None)
+    if pair is not None and fake.shape == hr.shape:
+        return pair(fake, hr)
+    return vgg(fake), vgg(hr)
+
+
 def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, optim_D, lr: Tensor, hr: Tensor,
                      scaler_G=None, scaler_D=None) -> Dict[str, Tensor]:
     """One iteration of the adversarial loop (train.py:196-223): the discriminator update on (hr, detached fake),
@@ -302,13 +381,13 @@ def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, 
     begin = getattr(optim_D, "begin_step", None) if scaler_D is None else None
     if begin is None:
         _backward_and_step(loss_D, optim_D, scaler_D)
-        feat_sr, feat_hr = vgg(fake), vgg(hr)
+        feat_sr, feat_hr = _perceptual_features(vgg, fake, hr)
     else:
         # data parallel: the two VGG19 forwards need neither D's gradients nor its new weights, so they are enqueued
         # while the all-reduce of D's gradients is in flight
         loss_D.backward()
         begin()
-        feat_sr, feat_hr = vgg(fake), vgg(hr)
+        feat_sr, feat_hr = _perceptual_features(vgg, fake, hr)
         optim_D.step()
 
     # The generator's loss needs the discriminator's input gradient only.  The reference's loss_G.backward() (:220) also

@@ -150,6 +150,34 @@ def test_vgg_gradient_chain_like_for_like():
     assert rel_l2(gx, gxr) < 0.25 and cosine(gx, gxr) > 0.97
 
 
+def test_vgg_pair_forward_is_the_two_separate_calls():
+    """VGGFeatureExtractor.forward_pair(sr, hr) — vgg(sr) and vgg(hr).detach() of esrgan/train.py:214-216 as one forward
+    over the concatenated batch, with the backward on the sr half only — against the two separate calls: the same
+    features and the same image gradient (a different batch size may select another kernel variant for a layer, hence
+    a bound instead of equality), no gradient path into hr."""
+    sd = O.make_vgg_state(7)
+    for k in sd:
+        sd[k] = sd[k] + 1.0 if k.endswith(".bias") else sd[k] * 0.2
+    vgg = S.VGGFeatureExtractor(pretrained=False)
+    vgg.load_state_dict(sd)
+    vgg = vgg.to(DEV)
+    gen = torch.Generator().manual_seed(21)
+    sr = torch.rand(4, 3, 64, 64, generator=gen).to(DEV).requires_grad_(True)
+    hr = torch.rand(4, 3, 64, 64, generator=gen).to(DEV)
+    f_sr, f_hr = vgg.forward_pair(sr, hr)
+    assert f_sr.requires_grad and not f_hr.requires_grad
+    loss = (f_sr - f_hr).abs().mean()
+    loss.backward()
+    g_pair = sr.grad.clone()
+    sr.grad = None
+    r_sr, r_hr = vgg(sr), vgg(hr)
+    (r_sr - r_hr.detach()).abs().mean().backward()
+    assert rel_l2(f_sr.detach(), r_sr.detach()) < 1e-3 and rel_l2(f_hr, r_hr) < 1e-3
+    assert rel_l2(g_pair, sr.grad) < 2e-2
+    with pytest.raises(RuntimeError):
+        vgg.forward_pair(sr, hr[:2])
+
+
 def test_adversarial_iteration_against_reference_run(golden):
     """G8 / esrgan/train.py:196-223: discriminator update then generator update (second forward, L1 + 0.01 * VGG-L1 +
     1e-3 * MSE(D(fake), 1)), Adam on both; losses, gradients and the BatchNorm bookkeeping of the reference run."""
