@@ -161,13 +161,16 @@ def _conv_forward(x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kin
 
 
 def _conv_backward(x: Tensor, weight: Tensor, bias: Tensor, dyb: Tensor, stride: int, need_dx: bool, need_dw: bool,
-                   dx_f32: bool = False, dy_split: bool = False):
+                   dx_f32: bool = False, dy_split: bool = False, gate: Optional[Tensor] = None, gate_slope: float = 1.0):
     """Data / weight / bias gradients of one conv from the blocked bf16 gradient ``dyb`` of its (pre-activation)
     output.  Stride 2: the data gradient reads ``dyb`` as its zero-inserted x2 image, the weight gradient likewise.
     ``dx_f32``: the data gradient as an fp32 tensor ``[N, H, cin/4, W, 4]`` (cin a multiple of 16) instead of blocked
     bf16 — for a consumer that subtracts means from it (a BatchNorm's backward).  ``dy_split``: ``dyb`` carries the
     gradient as hi + lo bf16 pairs (``to_blocked(..., split=1)``: channels [cout, 2 cout) hold the rounding residue); the
-    data gradient multiplies both, the weight gradient reads the hi part."""
+    data gradient multiplies both, the weight gradient reads the hi part.  ``gate`` (stride 1, blocked data gradient): a
+    blocked bf16 tensor of the data gradient's geometry whose sign gates it in the conv's epilogue — where the gate is not
+    positive the gradient is multiplied by ``gate_slope`` (0: the ReLU that produced this conv's input, whose output is
+    ``x`` itself)."""
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     N, H, U, W, _ = x.shape
     dx = dw = db = None
@@ -188,9 +191,11 @@ def _conv_backward(x: Tensor, weight: Tensor, bias: Tensor, dyb: Tensor, stride:
             alloc = torch.empty if U * 8 == n_out else torch.zeros
             dx = alloc((N, H, U, W, 8), dtype=torch.bfloat16, device=x.device)
             out_act, out_f32 = dx, None
+        if gate is not None and (stride != 1 or dx_f32 or gate.shape != dx.shape):
+            raise RuntimeError("conv3x3: a gated data gradient is a stride-1 conv with a blocked result of the gate's shape")
         if stride == 1:
             ops.conv3x3_fwd_now(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 0, None, 0.0, None, 0.0, out_act, 0,
-                                out_f32, None)
+                                out_f32, None, 0, gate, 0, float(gate_slope))
         else:
             ops.launch_conv(ops.conv_args(dyb, units_for(cout), wt, zero_bias, n_out, 1.0, 1, None, 0.0, None, 0.0, out_act,
                                           0, out_f32, None, zero_insert=True))

@@ -324,14 +324,22 @@ class _VGGPairFunction(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None
         g = ops.to_blocked_now(g_sr.float().contiguous(), ctx.units, DTYPE_BF16)
+        gated = False          # g already carries the derivative of the ReLU fused into the layer being visited
         for k in range(len(ctx.saved) - 1, -1, -1):
             kind, m, x, y = ctx.saved[k]
             if kind == "pool":
                 g = ops.maxpool2x2_bwd_now(x.contiguous(), g.contiguous())
+                gated = False
                 continue
-            if y is not None:
+            if y is not None and not gated:
                 g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
-            g, _dw, _db = cc._conv_backward(x.contiguous(), m.weight, m.bias, g.contiguous(), 1, True, False)
+            # where the layer below is a conv with a fused ReLU, this conv's input IS that ReLU's output: its
+            # derivative gates the data gradient in the conv's epilogue instead of in a pass of its own
+            below = ctx.saved[k - 1] if k > 0 else None
+            fuse = below is not None and below[0] == "conv" and below[3] is not None
+            g, _dw, _db = cc._conv_backward(x.contiguous(), m.weight, m.bias, g.contiguous(), 1, True, False,
+                                            gate=x.contiguous() if fuse else None, gate_slope=0.0)
+            gated = fuse
         return ops.from_blocked_now(g.contiguous(), 0, ctx.in_channels), None, None
 
 
