@@ -664,8 +664,9 @@ def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
         out["adversarial_step"] = {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
                                    "ms_per_step": round(el / steps * 1e3, 2),
                                    "scope": "D update + G update (one recorded G forward serving both, one G backward, three "
-                                            "D forwards, two D backwards plus one data-gradient-only pass, two VGG19 "
-                                            "forwards, one VGG19 data-gradient), Adam on both"}
+                                            "D forwards, two D backwards plus one data-gradient-only pass, the VGG19 "
+                                            "features of (fake, hr) as one batched forward, one VGG19 data-gradient "
+                                            "pass on the fake half), Adam on both"}
     except Exception as exc:
         out["adversarial_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
