@@ -589,7 +589,7 @@ def train_kernel_roofline(dev, batches=(16, 32, 64), size=32):
     return out
 
 
-def train_rate(dev, world, dist, steps=5, warmup=2, graph=False):
+def train_rate(dev, world, dist, steps=20, warmup=5, graph=False):
     """Extra figures beside the headline, on 16 LR patches of 32x32 (128x128 HR) per GPU (BASELINE config 3 shapes):
     * the pixel pre-training iteration (esrgan/train.py:157-163: G forward, L1, backward, Adam);
     * the adversarial iteration (:196-223: D update on (hr, fake), then G update with L1 + 0.01 VGG-L1 + 1e-3 GAN loss),
