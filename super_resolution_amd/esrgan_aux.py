@@ -85,8 +85,26 @@ class Discriminator(nn.Module):
         if torch.is_grad_enabled() and (img.requires_grad or any(p.requires_grad for p in params)):
             # recorded: the whole network is one autograd node whose backward keeps the gradients between the layers
             # in fp32 wherever a BatchNorm's backward consumes them
-            return _DiscriminatorFunction.apply(img, self, *params)
+            return _DiscriminatorFunction.apply(img, self, 1, *params)
         return self._forward_layers(img)
+
+    def forward_pair(self, real: Tensor, fake: Tensor) -> Tuple[Tensor, Tensor]:
+        """``(self(real), self(fake))`` — the two calls of the discriminator update (train.py:200-201) — as ONE pass over the
+        concatenated batch: every conv (and its data / weight gradient) runs once on both halves, every BatchNorm takes
+        its batch statistics per half and updates the running buffers with the real half first, then the fake half,
+        exactly as two calls do.  Same predictions and gradients, half the conv launches, no second accumulation into
+        ``.grad``."""
+        _need_cuda(real, "Discriminator")
+        if real.shape != fake.shape or real.device != fake.device:
+            raise RuntimeError("Discriminator.forward_pair: two batches of one shape on one device")
+        params = [p for p in self.parameters()]
+        n = int(real.shape[0])
+        both = torch.cat([real, fake], dim=0)
+        if torch.is_grad_enabled() and (both.requires_grad or any(p.requires_grad for p in params)):
+            pred = _DiscriminatorFunction.apply(both, self, 2, *params)
+        else:
+            pred = torch.cat([self._forward_layers(real), self._forward_layers(fake)], dim=0)
+        return pred[:n], pred[n:]
 
     def _forward_layers(self, img: Tensor) -> Tensor:
         mods = list(self.model)
@@ -120,8 +138,13 @@ class _DiscriminatorFunction(torch.autograd.Function):
     parameter gradient with one autograd node per layer), on fp32 ones it is not."""
 
     @staticmethod
-    def forward(ctx, img: Tensor, module: "Discriminator", *params: Tensor) -> Tensor:
+    def forward(ctx, img: Tensor, module: "Discriminator", groups: int, *params: Tensor) -> Tensor:
+        # groups: the batch is that many equal parts, each a batch of its own to every BatchNorm (statistics, running
+        # buffers updated part by part in order); convs and their gradients run over the whole batch
         layers = module._layers()
+        if groups < 1 or img.shape[0] % groups:
+            raise RuntimeError("Discriminator: the batch does not split into the requested groups")
+        part = int(img.shape[0]) // groups
         x = ops.to_blocked_now(img.detach().float().contiguous(), cc.units_for(img.shape[1]), DTYPE_BF16)
         saved = []
         out = None
@@ -143,25 +166,28 @@ class _DiscriminatorFunction(torch.autograd.Function):
                                        "momentum")
                 y32 = cc._conv_forward(x, w, b, 1.0, "f32", stride)
                 N, H, _q, W, _c = y32.shape
-                mean = torch.empty(cout, dtype=torch.float32, device=x.device)
-                rstd = torch.empty(cout, dtype=torch.float32, device=x.device)
+                mean = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
+                rstd = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
                 act = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=x.device)
                 training = bool(bn.training)
-                ops.bn_lrelu_fwd_now(y32, bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(slope), training,
-                                     float(bn.momentum), bn.running_mean, bn.running_var, bn.num_batches_tracked, mean,
-                                     rstd, act, 0)
+                for gi in range(groups):
+                    sl = slice(gi * part, (gi + 1) * part)
+                    ops.bn_lrelu_fwd_now(y32[sl], bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(slope),
+                                         training, float(bn.momentum), bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked, mean[gi], rstd[gi], act[sl], 0)
                 saved.append((x, y32, mean, rstd, training))
                 x = act
-        ctx.layers, ctx.saved, ctx.in_channels = layers, saved, int(img.shape[1])
+        ctx.layers, ctx.saved, ctx.in_channels, ctx.groups, ctx.part = layers, saved, int(img.shape[1]), groups, part
         return out
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         layers, saved = ctx.layers, ctx.saved
-        need = ctx.needs_input_grad          # (img, module, *params)
+        need = ctx.needs_input_grad          # (img, module, groups, *params)
+        groups, part = ctx.groups, ctx.part
         grads = []                           # per layer, in reverse: its parameters' gradients in parameter order
         g = None
-        p_at = 2 + sum(2 if bn is None else 4 for _c, bn, _s in layers)       # one past the last parameter
+        p_at = 3 + sum(2 if bn is None else 4 for _c, bn, _s in layers)       # one past the last parameter
         for k in range(len(layers) - 1, -1, -1):
             conv, bn, slope = layers[k]
             w, b, stride = conv.weight, conv.bias, int(conv.stride[0])
@@ -189,16 +215,21 @@ class _DiscriminatorFunction(torch.autograd.Function):
                 cout = int(w.shape[0])
                 N, H, _q, W, _c = y32.shape
                 dyb = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=y32.device)
-                dgamma = torch.empty(cout, dtype=torch.float32, device=y32.device)
-                dbeta = torch.empty(cout, dtype=torch.float32, device=y32.device)
-                ops.bn_lrelu_bwd_now(y32, g.contiguous(), bn.weight.detach(), bn.bias.detach(), mean, rstd, float(slope),
-                                     training, dyb, dgamma, dbeta, 0, 0)
+                dgamma = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
+                dbeta = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
+                g = g.contiguous()
+                for gi in range(groups):
+                    sl = slice(gi * part, (gi + 1) * part)
+                    ops.bn_lrelu_bwd_now(y32[sl], g[sl], bn.weight.detach(), bn.bias.detach(), mean[gi], rstd[gi],
+                                         float(slope), training, dyb[sl], dgamma[gi], dbeta[gi], 0, 0)
+                dgamma = dgamma[0] if groups == 1 else dgamma.sum(0)
+                dbeta = dbeta[0] if groups == 1 else dbeta.sum(0)
             dx, dw, db = cc._conv_backward(x, w, b, dyb, stride, need_dx, need_dw, dx_f32=dx_f32, dy_split=dy_split)
             grads.append([dw, db] if bn is None else [dw, db, dgamma, dbeta])
             g = dx
         d_img = ops.from_blocked_now(g.contiguous(), 0, ctx.in_channels) if need[0] else None
         flat = [t for layer in reversed(grads) for t in layer]
-        return (d_img, None, *flat)
+        return (d_img, None, None, *flat)
 
 
 _VGG19 = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
@@ -383,8 +414,12 @@ def adversarial_step(netG: nn.Module, netD: nn.Module, vgg: nn.Module, optim_G, 
     optim_D.zero_grad()
     optim_G.zero_grad()
     fake = netG(lr)
-    pred_real = netD(hr)
-    pred_fake = netD(fake.detach())
+    pair = getattr(netD, "forward_pair", None)
+    if pair is not None and hr.shape == fake.shape:
+        pred_real, pred_fake = pair(hr, fake.detach())       # one pass over both batches, BatchNorm per batch
+    else:
+        pred_real = netD(hr)
+        pred_fake = netD(fake.detach())
     loss_D = 0.5 * (cc.mse_loss(pred_real, 1.0) + cc.mse_loss(pred_fake, 0.0))
     begin = getattr(optim_D, "begin_step", None) if scaler_D is None else None
     if begin is None:

@@ -178,6 +178,41 @@ def test_vgg_pair_forward_is_the_two_separate_calls():
         vgg.forward_pair(sr, hr[:2])
 
 
+def test_discriminator_pair_pass_is_the_two_separate_calls():
+    """Discriminator.forward_pair(real, fake) — netD(real), netD(fake) of esrgan/train.py:200-201 as one pass over the
+    concatenated batch with BatchNorm statistics per half — against two calls on a twin network: the same predictions,
+    parameter gradients of 0.5 * (MSE(real, 1) + MSE(fake, 0)) and running buffers (real half first, then fake;
+    num_batches_tracked advances by two).  Convs of another batch size may run another kernel variant: bounds, not
+    equality."""
+    sd = O.make_discriminator_state(11)
+    nets = []
+    for _ in range(2):
+        net = S.Discriminator()
+        net.load_state_dict(sd)
+        nets.append(net.to(DEV).train())
+    a, b = nets
+    gen = torch.Generator().manual_seed(12)
+    real = torch.rand(4, 3, 64, 64, generator=gen).to(DEV)
+    fake = (torch.rand(4, 3, 64, 64, generator=gen) * 0.5).to(DEV)
+    pr, pf = a.forward_pair(real, fake)
+    (0.5 * (cc.mse_loss(pr, 1.0) + cc.mse_loss(pf, 0.0))).backward()
+    qr, qf = b(real), b(fake)
+    (0.5 * (cc.mse_loss(qr, 1.0) + cc.mse_loss(qf, 0.0))).backward()
+    assert rel_l2(pr.detach(), qr.detach()) < 2e-3 and rel_l2(pf.detach(), qf.detach()) < 2e-3
+    for (name, p), (_n, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_l2(p.grad, q.grad) < 3e-2, name
+    for (name, u), (_n, v) in zip(a.named_buffers(), b.named_buffers()):
+        if name.endswith("num_batches_tracked"):
+            assert int(u) == int(v) == 2, name
+        else:
+            assert rel_l2(u, v) < 1e-3, name
+    with torch.no_grad():
+        er, ef = a.forward_pair(real, fake)
+        assert er.shape == qr.shape and ef.shape == qf.shape
+    with pytest.raises(RuntimeError):
+        a.forward_pair(real, fake[:2])
+
+
 def test_adversarial_iteration_against_reference_run(golden):
     """G8 / esrgan/train.py:196-223: discriminator update then generator update (second forward, L1 + 0.01 * VGG-L1 +
     1e-3 * MSE(D(fake), 1)), Adam on both; losses, gradients and the BatchNorm bookkeeping of the reference run."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock time of the adversarial training iteration at the benchmark's training shape, steps issued back to back.
-python3 tools/time_adv.py [steps] [pair|separate]   (separate: the two VGG19 forwards as two calls)"""
+python3 tools/time_adv.py [steps] [pair|separate|dsep]   (separate: the two VGG19 forwards and the two discriminator passes
+of the D update as separate calls; dsep: only the discriminator passes separate)"""
 import os
 import sys
 import time
@@ -17,6 +18,8 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else "pair"
     if mode == "separate":
         esrgan_aux._perceptual_features = lambda vgg, fake, hr: (vgg(fake), vgg(hr))
+    if mode in ("separate", "dsep"):
+        S.Discriminator.forward_pair = None
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     netG = S.GeneratorRRDB().to(dev).train()
