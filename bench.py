@@ -663,10 +663,11 @@ def train_rate(dev, world, dist, steps=20, warmup=5, graph=False):
         assert bool(torch.isfinite(losses["loss_G"])) and bool(torch.isfinite(losses["loss_D"]))
         out["adversarial_step"] = {"value": round(world * 16 * steps / el, 1), "unit": "patches/s",
                                    "ms_per_step": round(el / steps * 1e3, 2),
-                                   "scope": "D update + G update (one recorded G forward serving both, one G backward, three "
-                                            "D forwards, two D backwards plus one data-gradient-only pass, the VGG19 "
-                                            "features of (fake, hr) as one batched forward, one VGG19 data-gradient "
-                                            "pass on the fake half), Adam on both"}
+                                   "scope": "D update + G update (one recorded G forward serving both, one G backward; the D "
+                                            "update's two passes (real, fake) as one batched forward + backward with "
+                                            "BatchNorm per half, a third D forward with its data-gradient-only pass for "
+                                            "the G loss; the VGG19 features of (fake, hr) as one batched forward, one "
+                                            "VGG19 data-gradient pass on the fake half), Adam on both"}
     except Exception as exc:
         out["adversarial_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
