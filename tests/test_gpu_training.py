@@ -345,6 +345,74 @@ def test_data_parallel_backward_two_ranks_one_gpu():
     assert ret["losses_finite"] and ret["replicas_equal"]
 
 
+def _rccl_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    from super_resolution_amd.ddp import DistributedGenerator, all_reduce_mean
+    from super_resolution_amd.sharded import sharded_forward
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    except Exception as exc:      # no RCCL on this box: nothing to test
+        ret["skip"] = f"{type(exc).__name__}: {exc}"
+        return
+    try:
+        sd = O.make_generator_state(61, num_blocks=3)
+        x = torch.rand(2, 3, 8, 8, generator=torch.Generator().manual_seed(62)).to(DEV)
+        ref_net = make_net(sd, 3)
+        ref_net(x).abs().mean().backward()
+        worst = {}
+        for alg in ("all_reduce", "direct"):
+            net = make_net(sd, 3)
+            dnet = DistributedGenerator(net, bucket_mb=1.0, algorithm=alg)
+            dnet.broadcast_parameters()
+            dnet(x).abs().mean().backward()
+            torch.cuda.synchronize()
+            worst[alg] = max(rel_l2(p.grad.cpu(), q.grad.cpu()) for p, q in zip(net.parameters(), ref_net.parameters()))
+            ret["buckets"] = len(dnet.buckets)
+        ret["worst"] = dict(worst)
+        buf = torch.arange(1000, dtype=torch.float32, device=DEV)
+        all_reduce_mean(buf, None, "direct")
+        ret["direct_identity"] = bool(torch.equal(buf.cpu(), torch.arange(1000, dtype=torch.float32)))
+        netD = S.Discriminator().to(DEV).train()
+        optD = S.FlatAdam(netD.parameters(), lr=1e-4, reduce_group=dist.group.WORLD)
+        before = torch.cat([p.detach().flatten() for p in netD.parameters()]).clone()
+        netD(torch.rand(2, 3, 64, 64, device=DEV)).mean().backward()
+        optD.begin_step()
+        optD.step()
+        after = torch.cat([p.detach().flatten() for p in netD.parameters()])
+        ret["d_stepped"] = bool(torch.isfinite(after).all() and not torch.equal(before, after))
+        with torch.no_grad():
+            img = torch.rand(1, 3, 24, 20, generator=torch.Generator().manual_seed(63)).to(DEV)
+            inf = make_net(sd, 3).eval()
+            whole = inf(img)
+            got = sharded_forward(inf, img, halo=64)
+        ret["sharded_equal"] = bool(got is not None and torch.equal(got, whole))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_code_paths_run_with_one_rank():
+    """The collectives of the multi-GPU paths on RCCL itself (backend "nccl", device tensors — the gloo tests stage through
+    host memory): one rank is all a one-GPU box offers, so every mean is the identity, but the bucketed asynchronous
+    all-reduce overlapped with the phased backward, the direct reduce-scatter + all-gather (all-to-all), the
+    discriminator's flat-buffer all-reduce started before and awaited in its optimizer step, and the tile-sharded
+    forward's gather all execute as they would across GPUs (esrgan/train.py:108-111, test.py:71-72)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    if "skip" in ret:
+        pytest.skip("RCCL could not be initialised here: " + ret["skip"])
+    assert ret["buckets"] >= 2
+    assert all(v == 0.0 for v in ret["worst"].values()), dict(ret["worst"])     # a mean over one rank changes nothing
+    assert ret["direct_identity"] and ret["d_stepped"] and ret["sharded_equal"]
+
+
 def test_data_parallel_replica_routes_gradients_through_autograd():
     """esrgan/train.py:108-111 wraps the generator in nn.DataParallel: a replica's parameters are broadcast outputs,
     not leaves, so the backward must hand their gradients to autograd (which carries them back to the originals)
