@@ -63,6 +63,25 @@ def test_cpu_tensors_fail_loudly():
         net(torch.rand(1, 4, 8, 8))
 
 
+def test_batched_pair_calls_have_no_cpu_fallback_either():
+    """Discriminator.forward_pair / VGGFeatureExtractor.forward_pair (the two calls of esrgan/train.py:200-201 and
+    :214-216 as one pass) refuse CPU tensors and mismatched batches like the plain calls, and the multi-block weight
+    gradient refuses an empty or over-long block list before it touches the library."""
+    from super_resolution_amd import ops
+    d, v = S.Discriminator(), S.VGGFeatureExtractor(pretrained=False)
+    a, b = torch.rand(2, 3, 32, 32), torch.rand(2, 3, 32, 32)
+    for net in (d, v):
+        with pytest.raises(RuntimeError, match="only on a ROCm device"):
+            net.forward_pair(a, b)
+    with pytest.raises(RuntimeError):
+        ops.launch_dense_wgrad_blocks([])
+    with pytest.raises(RuntimeError):
+        ops.launch_dense_wgrad_blocks([None] * (ops.DENSE_WGRAD_MAX_BLOCKS + 1))
+    plan = v._plan()
+    assert [k for k, _m, _r in plan].count("conv") == 16 and [k for k, _m, _r in plan].count("pool") == 4
+    assert plan[-1][0] == "conv" and plan[-1][2] is False          # features[:35] ends in conv5_4 without its ReLU
+
+
 def test_discriminator_state_dict_matches_reference_manifest():
     """Keys, shapes and dtypes of the reference Discriminator's state_dict (tests/golden/g6_disc_manifest.txt)."""
     net = S.Discriminator()

@@ -20,11 +20,17 @@ def main():
     torch.manual_seed(0)
     net = S.GeneratorRRDB().to(dev).eval()
     x = torch.rand(B, 3, L, L, device=dev)
-    if os.environ.get("TIME_CHAIN_ZEROS") == "1":      # all-zero operands: the same traffic at the clock an idle matrix pipe allows
-        with torch.no_grad():
+    zeros = os.environ.get("TIME_CHAIN_ZEROS", "0")
+    if zeros in ("1", "2"):      # 1: all-zero operands (the same traffic at the clock an idle matrix pipe allows); 2: zero
+        with torch.no_grad():    # weights only: random activations move through LDS and the fabric, the products are zero
             for p in net.parameters():
                 p.zero_()
-        x.zero_()
+        if zeros == "1":
+            x.zero_()
+    if zeros == "3":             # 3: zero body weights, ones as biases: constant non-zero activations
+        with torch.no_grad():
+            for n_, p in net.named_parameters():
+                p.zero_() if n_.endswith("weight") else p.fill_(1.0)
     L_ = _lib.lib()
     L_.sr355_chain_timing(1)
     L_.sr355_chain_last_ms.restype = __import__("ctypes").c_float
