@@ -35,6 +35,9 @@ def run(net, x, chain, perm=False):
     ((16, 3, 128, 128), 3, {"dense_skip_fp32": True}),           # the benchmark batch, an fp32 carrier for every skip
     ((3, 3, 200, 330), 2, {"hr_f16": False}),                    # ragged edges: 13 x 11 tiles per image
     ((40, 3, 128, 96), 1, {}),                                   # more tiles (960) than resident workgroups
+    ((1, 3, 512, 256), 1, {}),                                   # one image, exactly as many tiles as the threshold
+    ((1, 3, 16, 8192), 1, {}),                                   # one row of 256 tiles: left / right neighbours only
+    ((1, 3, 4100, 32), 1, {}),                                   # one column of 257 tiles, the last one partial
 ])
 def test_chain_is_bit_identical_to_one_launch_per_conv(shape, blocks, kw):
     sd = O.center_outputs(O.make_generator_state(7, num_blocks=blocks), 0.5)
