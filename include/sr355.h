@@ -198,7 +198,7 @@ typedef struct sr355_wgrad_args {
     const void *in_dev; size_t in_bytes; int in_units;
     int cin;                   /* real input channels (channels [0, cin) of `in`) */
     const void *dy_dev; size_t dy_bytes; int dy_units, dy_unit_off;
-    int cout;                  /* <= 64, or a multiple of 32 up to 4096 (32-channel slices as jobs of one launch) */
+    int cout;                  /* 1 .. 4096 (above 64: 32-channel slices as the jobs of one launch) */
     float scale;
     int accumulate;            /* 0: overwrite dw/db, 1: add into them */
     float *dw_dev; size_t dw_bytes;

@@ -488,7 +488,7 @@ int sr355_pool2x2_sum(const void *in, size_t in_bytes, int N, int H, int W, int 
 }
 
 size_t sr355_wgrad_workspace_bytes(int cout, int cin, int N, int H, int W) {
-    if (cout < 1 || cin < 1 || N < 1 || H < 1 || W < 1 || (cout > 64 && (cout & 31)) || cout > 4096) return 0;
+    if (cout < 1 || cin < 1 || N < 1 || H < 1 || W < 1 || cout > 4096) return 0;
     return wgrad_workspace_bytes(cout, cin, N, H, W);
 }
 
@@ -498,7 +498,7 @@ static int wgrad_checks(const char *who, const sr355_wgrad_args *p, const void *
         set_error("%s: args is null", who);
         return SR355_ERR_INVALID;
     }
-    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || (p->cout > 64 && (p->cout & 31)) || p->cout > 4096 ||
+    if (p->N < 1 || p->H < 1 || p->W < 1 || p->cout < 1 || p->cout > 4096 ||
         p->cin < 1 ||
         (p->upsample != 0 && p->upsample != 1) || (p->upsample && ((p->H | p->W) & 1))) {
         set_error("%s: bad shape N=%d H=%d W=%d cout=%d cin=%d upsample=%d", who, p->N, p->H, p->W, p->cout,
@@ -1547,8 +1547,8 @@ static Saved carve_saved(const sr355_generator_cfg &c, const Workspace &ws, int 
 
 static bool train_ok(const sr355_generator_cfg *cfg) {
     if (!cfg_ok(cfg)) return false;
-    if (cfg->dtype != SR355_DTYPE_BF16 || cfg->num_features > 64 || cfg->growth_channels > 64) {
-        set_error("training path: bf16 kernels with num_features, growth_channels <= 64 only");
+    if (cfg->dtype != SR355_DTYPE_BF16) {
+        set_error("training path: bf16 kernels only (the exact-fp32 path trains conv by conv)");
         return false;
     }
     if (cfg->hr_split == SR355_HR_F16 || cfg->trunk_fp32 == SR355_TRUNK_RRDB) {
@@ -1616,7 +1616,11 @@ static BwdPack carve_bwd(const sr355_generator_cfg &c) {
         off += align256(bytes);
         return o;
     };
-    p.zero_bias = take(64 * sizeof(float));
+    {   // one all-zero bias for every data-gradient conv: as long as the widest of them
+        int widest = nf > gc ? nf : gc;
+        if (c.in_channels > widest) widest = c.in_channels;
+        p.zero_bias = take((size_t)(cout_pad_for(widest) < 64 ? 64 : cout_pad_for(widest)) * sizeof(float));
+    }
     p.rdb.resize((size_t)3 * c.num_blocks * 5);
     for (int i = 0; i < 3 * c.num_blocks; ++i)
         for (int j = 4; j >= 0; --j) {
@@ -1855,6 +1859,7 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // time of the call (measured at 16 x 32 x 32: 7.2 ms per pixel iteration with the side stream, 6.8 without;
     // with one launch per conv, 64 x 64 and up, the side stream gains 2-10 %).  SR355_WGRAD_STREAM=0 / 1 forces it.
     const bool fused = use_dense_fused(cfg, N, H, W);
+    const bool block_wgrad_ok = cout_pad_for(gc) == 32 && cout_pad_for(nf) <= 64;   // what launch_wgrad3x3_blocks takes
     static const int side_knob = [] { const char *e = getenv("SR355_WGRAD_STREAM"); return e ? atoi(e) : -1; }();
     SideStream *ss = (side_knob < 0 ? !fused : side_knob != 0) ? side_stream() : nullptr;
     std::unique_lock<std::mutex> side_lock;
@@ -2067,7 +2072,18 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
                 if (ss && (check_hip(hipEventRecord(ss->main_mark, stream), "hipEventRecord") ||
                            check_hip(hipStreamWaitEvent(wstream, ss->main_mark, 0), "hipStreamWaitEvent")))
                     return SR355_ERR_HIP;
-                if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
+                if (block_wgrad_ok) {
+                    if ((rc = launch_wgrad3x3_block(A, GB[cur], bu, nf, gc, N, H, W, s5, dw, db, slabs, wstream))) return rc;
+                } else {
+                    // widths the batched launch is not built for (growth above 32, features above 64): conv by conv
+                    for (int k = 0; k < 5; ++k) {
+                        const int cin = nf + k * gc, cout = k < 4 ? gc : nf;
+                        const int dy_unit = k < 4 ? (nf + (3 - k) * gc) / 8 : 0;   // stack order: dOut, dY4, dY3, dY2, dY1
+                        if ((rc = launch_wgrad3x3(A, bu, 0, GB[cur], bu, dy_unit, N, H, W, cout, cin, k < 4 ? 1.f : s5, 0,
+                                                  dw[k], db[k], slabs, wstream)))
+                            return rc;
+                    }
+                }
             }
             const int nxt = (cur + 1) % n_gb;
             // the next write goes to GB[nxt] units [0, nf): the conv5 weight gradient of the dense block before

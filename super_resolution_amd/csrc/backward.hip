@@ -754,22 +754,20 @@ int launch_wgrad_reduce(const float *slabs, float *dw, int cout, int cin, int CO
     return check_hip(hipGetLastError(), "wgrad reduce launch");
 }
 
-// A conv with more than 64 output channels (a multiple of 32): its 32-output slices are the jobs of batched launches
+// A conv with more than 64 output channels: its 32-output slices are the jobs of batched launches
 // (blockIdx.z = slice, all reading the same input), WGRAD_MAX_JOBS slices per launch, each followed by one batched
 // reduction.  One launch per 64 outputs would leave most of the chip idle at the small images such layers have.
 static int launch_wgrad3x3_sliced(const void *in, int in_units, int ups, const void *dy, int dy_units, int dy_unit_off,
                                   int N, int H, int W, int cout, int cin, float scale, int accumulate, float *dw,
                                   float *db, float *slabs, hipStream_t stream, int dy_stride2) {
-    if (cout & 31) {
-        set_error("wgrad3x3: cout=%d not supported (more than 64 output channels must be a multiple of 32)", cout);
-        return SR355_ERR_UNSUPPORTED;
-    }
     int rc;
     if ((rc = wgrad_set_attr(0))) return rc;
     int chunks, G;
     wgrad_geometry(cin, N, H, W, &chunks, &G);
     const size_t slice_floats = wgrad_slice_floats(cin, N, H, W);
-    const int n_slices = cout / 32;
+    // (a last slice of fewer than 32 outputs: its workgroups still multiply four units of dy -- whatever lies behind
+    // the conv's own units in the image, zeros past its end -- into slab rows the reduction never reads)
+    const int n_slices = (cout + 31) / 32;
     for (int s0 = 0; s0 < n_slices; s0 += WGRAD_MAX_JOBS) {
         const int m = n_slices - s0 < WGRAD_MAX_JOBS ? n_slices - s0 : WGRAD_MAX_JOBS;
         WgradArgs a;
@@ -795,7 +793,7 @@ static int launch_wgrad3x3_sliced(const void *in, int in_units, int ups, const v
             a.z_slab_off[k] = (long long)off;
             a.z_bias_off[k] = db ? (long long)bias_off : -1;
             rt.j[k] = WgradReduceJob{slabs + off, slabs + bias_off, dw + (size_t)sl * 32 * cin * 9, db ? db + sl * 32 : nullptr,
-                                     32, cin, 32, G, scale};
+                                     cout - sl * 32 < 32 ? cout - sl * 32 : 32, cin, 32, G, scale};
         }
         hipLaunchKernelGGL(wgrad3x3_kernel_mb1, dim3(G, chunks, m), dim3(192), WGeo<1>::LDS_BYTES, stream, a);
         if (check_hip(hipGetLastError(), "wgrad3x3 sliced launch")) return SR355_ERR_HIP;

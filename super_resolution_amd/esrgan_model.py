@@ -138,7 +138,7 @@ class ResidualDenseBlock(nn.Module):
         dev = act.device
         stack = ops.to_blocked(g, act.shape[2], DTYPE_BF16)            # units [0, nf/8): dOut
         packs = self._packed_bwd()
-        zero = torch.zeros(64, dtype=torch.float32, device=dev)
+        zero = torch.zeros(max(64, (max(nf, gc) + 31) // 32 * 32), dtype=torch.float32, device=dev)
         dxc = torch.empty((N, H, nf // 4, W, 4), dtype=torch.float32, device=dev)
         mask_off = [(nf + (3 - k) * gc) // 8 for k in range(4)]
         if W <= ops.DENSE_BLOCK_MAX_WIDTH and nf == 64 and gc == 32:

@@ -441,9 +441,8 @@ def _(act, stack, nf, gc, growth_scale, conv5_scale, dw, db):
 
 def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tensor, db: Tensor,
                       stride: int = 1) -> None:
-    """Weight / bias gradient of a conv with any number of output channels.  Up to 64, or any multiple of 32, is one
-    ``sr355_conv3x3_wgrad`` call (the library runs the 32-channel slices of a wide layer as the jobs of one batched
-    launch); other widths are walked in 64-channel slices with one argument block, workspace and device context."""
+    """Weight / bias gradient of a conv with any number of output channels: one ``sr355_conv3x3_wgrad`` call per 4096
+    outputs (the library runs the 32-channel slices of a wide layer as the jobs of one batched launch)."""
     _need_cuda(in_buf, dy, dw, db)
     if in_buf.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
         raise RuntimeError("conv3x3_wgrad runs on bf16 activations")
@@ -457,7 +456,7 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
     a.in_dev, a.in_bytes, a.in_units, a.cin = in_buf.data_ptr(), _nbytes(in_buf), int(in_buf.shape[2]), int(cin)
     a.dy_dev, a.dy_bytes, a.dy_units = dy.data_ptr(), _nbytes(dy), int(dy.shape[2])
     a.scale, a.accumulate = 1.0, 0
-    step = cout if (cout <= 64 or cout % 32 == 0) else 64
+    step = min(cout, 4096)
     need = L.sr355_wgrad_workspace_bytes(step, cin, N, H, W)
     if need == 0:
         raise RuntimeError("conv3x3_wgrad: unsupported shape")

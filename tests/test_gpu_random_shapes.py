@@ -36,7 +36,13 @@ def draw_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("case", draw_cases(36, 20240607), ids=lambda c: "n%d_ci%d_co%d_%dx%d_s%d_a%g" % c)
+# output widths that are neither a 32-channel block nor within one 64-channel launch of the weight gradient (its last slice
+# is ragged), and input widths that are not whole 32-channel chunks
+RAGGED = [(2, 40, 72, 9, 33, 1, 0.2), (1, 64, 80, 17, 16, 1, 1.0), (2, 24, 200, 5, 8, 2, 0.2), (1, 104, 136, 8, 31, 1, 0.0),
+          (3, 8, 88, 4, 65, 2, 1.0)]
+
+
+@pytest.mark.parametrize("case", draw_cases(36, 20240607) + RAGGED, ids=lambda c: "n%d_ci%d_co%d_%dx%d_s%d_a%g" % c)
 def test_conv_forward_and_gradients_on_random_shapes(case):
     N, cin, cout, H, W, stride, slope = case
     g = torch.Generator().manual_seed(hash(case) & 0xffff)
