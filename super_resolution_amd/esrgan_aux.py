@@ -28,6 +28,14 @@ from ._lib import DTYPE_BF16
 def _need_cuda(x: Tensor, who: str) -> None:
     if not x.is_cuda:
         raise RuntimeError(f"{who} runs only on a ROCm device (got a {x.device.type} tensor)")
+    if x.dim() != 4:
+        raise RuntimeError(f"{who}: expected an NCHW tensor, got {tuple(x.shape)}")
+    if not x.is_floating_point():
+        # nn.Conv2d refuses it the same way
+        raise RuntimeError(f"{who}: Input type ({x.dtype}) and weight type (torch.float32) should be the same")
+    if x.shape[0] and (x.shape[2] == 0 or x.shape[3] == 0):
+        raise RuntimeError(f"{who}: Kernel size (3 x 3) can't be greater than the padded input size "
+                           f"({x.shape[2] + 2} x {x.shape[3] + 2})")
 
 
 class Discriminator(nn.Module):
@@ -79,8 +87,27 @@ class Discriminator(nn.Module):
             raise RuntimeError("Discriminator: expected conv blocks with an activation and one final plain conv")
         return out
 
+    def _check_batch(self, n: int, h: int, w: int) -> None:
+        """nn.BatchNorm2d's own refusal of a training batch with one value per channel (the deepest normalised layer
+        sees the fewest)."""
+        for _k in range(4):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        if self.training and n * h * w == 1 and any(isinstance(m, nn.BatchNorm2d) and m.training for m in self.model):
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([{n}, {self.model[-1].in_channels}, {h}, {w}])")
+
+    @staticmethod
+    def _empty_result(img: Tensor) -> Tensor:
+        h, w = int(img.shape[2]), int(img.shape[3])
+        for _k in range(4):
+            h, w = (h + 1) // 2, (w + 1) // 2
+        return img.new_zeros((0, 1, h, w), dtype=torch.float32)
+
     def forward(self, img: Tensor) -> Tensor:
         _need_cuda(img, "Discriminator")
+        if img.shape[0] == 0:
+            return self._empty_result(img)
+        self._check_batch(int(img.shape[0]), int(img.shape[2]), int(img.shape[3]))
         params = [p for p in self.parameters()]
         if torch.is_grad_enabled() and (img.requires_grad or any(p.requires_grad for p in params)):
             # recorded: the whole network is one autograd node whose backward keeps the gradients between the layers
@@ -97,6 +124,9 @@ class Discriminator(nn.Module):
         _need_cuda(real, "Discriminator")
         if real.shape != fake.shape or real.device != fake.device:
             raise RuntimeError("Discriminator.forward_pair: two batches of one shape on one device")
+        if real.shape[0] == 0:
+            return self._empty_result(real), self._empty_result(fake)
+        self._check_batch(int(real.shape[0]), int(real.shape[2]), int(real.shape[3]))
         params = [p for p in self.parameters()]
         n = int(real.shape[0])
         both = torch.cat([real, fake], dim=0)
@@ -273,6 +303,8 @@ class VGGFeatureExtractor(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         _need_cuda(x, "VGGFeatureExtractor")
+        if x.shape[0] == 0:
+            return self._empty_result(x)
         mods = list(self.features)
         h = cc.to_blocked(x)
         channels = x.shape[1]
@@ -294,6 +326,16 @@ class VGGFeatureExtractor(nn.Module):
                 raise RuntimeError(f"unexpected layer {type(m).__name__} in the VGG feature stack")
         return cc.from_blocked(h, channels)
 
+
+    def _empty_result(self, x: Tensor) -> Tensor:
+        """The features of a batch of no images: ``[0, C, h, w]`` with the stack's output geometry."""
+        c, h, w = int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
+        for m in self.features:
+            if isinstance(m, nn.Conv2d):
+                c = m.out_channels
+            elif isinstance(m, nn.MaxPool2d):
+                h, w = h // 2, w // 2
+        return x.new_zeros((0, c, h, w), dtype=torch.float32)
 
     def _plan(self) -> list:
         """The feature stack as (kind, module, relu) steps: "conv" with its fused ReLU flag, "pool"."""
@@ -321,6 +363,8 @@ class VGGFeatureExtractor(nn.Module):
         _need_cuda(sr, "VGGFeatureExtractor")
         if sr.shape != hr.shape or sr.device != hr.device:
             raise RuntimeError("VGGFeatureExtractor.forward_pair: two batches of one shape on one device")
+        if sr.shape[0] == 0:
+            return self._empty_result(sr) + sr.float().sum() * 0, self._empty_result(hr)
         return _VGGPairFunction.apply(sr, hr, self)
 
 

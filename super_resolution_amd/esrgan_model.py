@@ -168,6 +168,8 @@ class ResidualDenseBlock(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
+        if x.shape[0] == 0:
+            return _empty_result(x, self.in_channels, 1, list(self.parameters()))
         dtype = _PRECISIONS[self.precision]
         if _records_graph(self, x):
             if dtype != DTYPE_BF16:        # exact-fp32 training: one autograd node per conv
@@ -195,6 +197,8 @@ class RRDB(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
+        if x.shape[0] == 0:
+            return _empty_result(x, self.in_channels, 1, list(self.parameters()))
         dtype = _PRECISIONS[self.precision]
         if _records_graph(self, x):
             if dtype != DTYPE_BF16:
@@ -338,6 +342,8 @@ class GeneratorRRDB(nn.Module):
     # -- forward --------------------------------------------------------------------------
     def forward(self, x: Tensor) -> Tensor:
         _check_input(x, self.in_channels)
+        if x.shape[0] == 0:
+            return _empty_result(x, self.out_channels, 4, list(self.parameters()))
         xin = x.float().contiguous()
         params = self.conv_parameters()
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
@@ -471,6 +477,22 @@ def _check_input(x: Tensor, channels: int) -> None:
     if not x.is_cuda:
         raise RuntimeError("super_resolution_amd runs on ROCm devices only: move the module and its input to "
                            "'cuda' (there is no CPU fallback)")
+    if not x.is_floating_point():
+        # nn.Conv2d refuses it the same way ("Input type ... and weight type ... should be the same")
+        raise RuntimeError(f"Input type ({x.dtype}) and weight type (torch.float32) should be the same: pass a "
+                           "floating-point tensor (images as bytes go through upscale_u8)")
+    if x.shape[0] and (x.shape[2] == 0 or x.shape[3] == 0):
+        raise RuntimeError(f"Kernel size (3 x 3) can't be greater than the padded input size "
+                           f"({x.shape[2] + 2} x {x.shape[3] + 2})")
+
+
+def _empty_result(x: Tensor, channels: int, scale: int, params) -> Tensor:
+    """What the reference's convs return for a batch of no images: ``[0, channels, scale H, scale W]``, connected to the
+    graph (all-zero gradients) where one is recorded."""
+    out = x.new_zeros((0, channels, scale * x.shape[2], scale * x.shape[3]), dtype=torch.float32)
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        out = out + x.float().sum() * 0 + sum(p.sum() for p in params if p.requires_grad) * 0
+    return out
 
 
 def _records_graph(module: nn.Module, x: Tensor) -> bool:

@@ -1,0 +1,108 @@
+"""GPU: what the drop-in modules do with the inputs a PyTorch caller can hand the reference's
+(/root/reference/esrgan/models/esrgan_model.py:55-62, :86-87, :102-103): views that are not contiguous, other floating
+dtypes, a batch of no images, and the inputs nn.Conv2d / nn.BatchNorm2d themselves refuse."""
+import pytest
+import torch
+
+from oracle import esrgan_oracle as O
+import super_resolution_amd as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def net():
+    sd = O.center_outputs(O.make_generator_state(5, num_blocks=1))
+    m = S.GeneratorRRDB(num_blocks=1)
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+def test_generator_reads_any_memory_format(net):
+    x = torch.rand(2, 3, 12, 20, device=DEV)
+    with torch.no_grad():
+        ref = net(x)
+        assert torch.equal(net(x.contiguous(memory_format=torch.channels_last)), ref)
+        big = torch.rand(2, 3, 24, 40, device=DEV)
+        big[:, :, ::2, 1::2] = x
+        assert torch.equal(net(big[:, :, ::2, 1::2]), ref)
+        assert torch.equal(net(x[:1].expand(2, 3, 12, 20)), net(x[:1].repeat(2, 1, 1, 1)))
+        assert torch.equal(net(x.double()), ref)                         # every floating dtype is read as fp32
+        assert (net(x.half()) - ref).abs().max().item() < 2e-3           # (the input's own rounding)
+    # recorded forward and backward through a channels_last leaf
+    net.train()
+    try:
+        a = x.clone().requires_grad_(True)
+        b = x.contiguous(memory_format=torch.channels_last).clone().requires_grad_(True)
+        net(a).square().sum().backward()
+        ga = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        net(b).square().sum().backward()
+        assert torch.equal(a.grad, b.grad)
+        assert all(torch.equal(g, p.grad) for g, p in zip(ga, net.parameters()))
+    finally:
+        net.zero_grad()
+        net.eval()
+
+
+def test_generator_refuses_what_conv2d_refuses(net):
+    with pytest.raises(RuntimeError, match="should be the same"):
+        net(torch.zeros(1, 3, 8, 8, dtype=torch.uint8, device=DEV))
+    with pytest.raises(RuntimeError, match="NCHW"):
+        net(torch.zeros(3, 8, 8, device=DEV))
+    with pytest.raises(RuntimeError, match="NCHW"):
+        net(torch.zeros(1, 4, 8, 8, device=DEV))
+    with pytest.raises(RuntimeError, match="Kernel size"):
+        net(torch.zeros(1, 3, 0, 8, device=DEV))
+
+
+@pytest.mark.parametrize("cls", ["generator", "rrdb", "block"])
+def test_a_batch_of_no_images_gives_no_images(cls, net):
+    """nn.Conv2d maps [0, C, H, W] to [0, C', H, W]; a recorded call leaves all-zero gradients."""
+    if cls == "generator":
+        m, x, shape = net, torch.zeros(0, 3, 12, 20, device=DEV), (0, 3, 48, 80)
+    elif cls == "rrdb":
+        m, x, shape = S.RRDB(64, 32).to(DEV), torch.zeros(0, 64, 6, 5, device=DEV), (0, 64, 6, 5)
+    else:
+        m, x, shape = S.ResidualDenseBlock(64, 32).to(DEV), torch.zeros(0, 64, 6, 5, device=DEV), (0, 64, 6, 5)
+    with torch.no_grad():
+        out = m(x)
+    assert out.shape == shape and out.dtype == torch.float32 and out.device == x.device
+    m.train()
+    try:
+        xg = x.clone().requires_grad_(True)
+        out = m(xg)
+        assert out.shape == shape and out.requires_grad
+        out.sum().backward()
+        assert xg.grad is not None and xg.grad.shape == x.shape
+        assert all(p.grad is not None and not bool(p.grad.any()) for p in m.parameters())
+    finally:
+        m.zero_grad()
+        m.eval()
+
+
+def test_discriminator_and_vgg_input_contract():
+    D = S.Discriminator().to(DEV)
+    V = S.VGGFeatureExtractor(pretrained=False).to(DEV).eval()
+    x = torch.rand(2, 3, 48, 40, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(V(x.contiguous(memory_format=torch.channels_last)), V(x))
+        assert V(x[:0]).shape == (0, 512, 3, 2)
+        assert V(torch.rand(1, 3, 50, 70, device=DEV)).shape == (1, 512, 3, 4)      # MaxPool2d floors odd sizes
+        D.eval()
+        assert torch.equal(D(x.contiguous(memory_format=torch.channels_last)), D(x))
+        assert D(x[:0]).shape == (0, 1, 3, 3)
+        assert D(torch.rand(2, 3, 50, 41, device=DEV)).shape == (2, 1, 4, 3)        # stride 2 / pad 1 rounds up
+        assert D(torch.rand(1, 3, 16, 16, device=DEV)).shape == (1, 1, 1, 1)        # running statistics: any size
+    for m in (D, V):
+        with pytest.raises(RuntimeError, match="should be the same"):
+            m(torch.zeros(1, 3, 16, 16, dtype=torch.uint8, device=DEV))
+        with pytest.raises(RuntimeError, match="NCHW"):
+            m(torch.zeros(3, 16, 16, device=DEV))
+    D.train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):          # nn.BatchNorm2d's own refusal
+        D(torch.rand(1, 3, 16, 16, device=DEV))
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        D.forward_pair(torch.rand(1, 3, 16, 16, device=DEV), torch.rand(1, 3, 16, 16, device=DEV))
+    assert D(torch.rand(2, 3, 16, 16, device=DEV)).shape == (2, 1, 1, 1)
