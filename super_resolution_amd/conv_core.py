@@ -17,6 +17,7 @@ from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from . import ops
 from ._lib import DTYPE_BF16
@@ -38,6 +39,7 @@ class _ToBlocked(torch.autograd.Function):
         return ops.to_blocked_now(x.detach().float().contiguous(), units_for(x.shape[1]), DTYPE_BF16)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         return ops.from_blocked_now(g.contiguous(), 0, ctx.channels)
 
@@ -49,6 +51,7 @@ class _FromBlocked(torch.autograd.Function):
         return ops.from_blocked_now(buf.detach().contiguous(), 0, channels)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         return ops.to_blocked_now(g.float().contiguous(), ctx.units, DTYPE_BF16), None
 
@@ -216,6 +219,7 @@ class _Conv3x3(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy: Tensor):
         x, weight, bias, y = ctx.saved_tensors
         cout = int(weight.shape[0])
@@ -279,6 +283,7 @@ class _ConvBnAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy: Tensor):
         x, weight, bias, gamma, beta, y32, mean, rstd = ctx.saved_tensors
         cout = int(weight.shape[0])
@@ -334,6 +339,7 @@ class _ConvAdd(torch.autograd.Function):
         return new_trunk, act
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_trunk, g_act):
         x, weight, bias = ctx.saved_tensors
         total = g_trunk
@@ -358,6 +364,7 @@ class _PixelShuffle2(torch.autograd.Function):
         return ops.pixel_shuffle2_now(x.contiguous(), False)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         return ops.pixel_shuffle2_now(g.contiguous(), True)
 
@@ -397,6 +404,7 @@ class _MaxPool2x2(torch.autograd.Function):
         return ops.maxpool2x2_fwd_now(x)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         (x,) = ctx.saved_tensors
         return ops.maxpool2x2_bwd_now(x, g.contiguous())
@@ -418,6 +426,7 @@ class _MeanLoss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         (grad,) = ctx.saved_tensors
         ga = grad * g

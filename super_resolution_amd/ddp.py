@@ -244,6 +244,8 @@ class DistributedGenerator(nn.Module):
                 p.data.copy_(host)
             else:
                 dist.broadcast(p.data, src=src, group=self.group)
+        # writes through .data do not move the parameters' version counters, which is what the weight-pack caches look at
+        torch.autograd.graph.increment_version(list(self.module.parameters()))
 
     def forward(self, x: Tensor) -> Tensor:
         from .esrgan_model import _GeneratorFunction, _graph_params

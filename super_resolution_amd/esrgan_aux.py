@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from . import conv_core as cc
 from . import ops
@@ -211,6 +212,7 @@ class _DiscriminatorFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy: Tensor):
         layers, saved = ctx.layers, ctx.saved
         need = ctx.needs_input_grad          # (img, module, groups, *params)
@@ -395,6 +397,7 @@ class _VGGPairFunction(torch.autograd.Function):
         return f_sr, f_hr
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_sr: Tensor, _g_hr):
         if not ctx.needs_input_grad[0]:
             return None, None, None

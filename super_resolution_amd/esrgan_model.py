@@ -21,6 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from . import fp32_train, ops
 from ._lib import DTYPE_BF16, DTYPE_F32, HR_F16, TRUNK_RRDB, Sr355Error
@@ -86,7 +87,7 @@ class ResidualDenseBlock(nn.Module):
 
     def _packed(self, dtype: int):
         params = [p for c in self._convs() for p in (c.weight, c.bias)]
-        return self._cache.get(params, dtype, lambda: [ops.pack_weight(c.weight.detach(), c.bias.detach(), dtype)
+        return self._cache.get(params, dtype, lambda: [ops.pack_weight(c.weight.detach().float(), c.bias.detach().float(), dtype)
                                                         for c in self._convs()], not _is_replica(self))
 
     def _run(self, buf: Tensor, trunk_in: Tensor, trunk_out: Tensor, nxt: Tensor, dtype: int,
@@ -171,17 +172,21 @@ class ResidualDenseBlock(nn.Module):
         if x.shape[0] == 0:
             return _empty_result(x, self.in_channels, 1, list(self.parameters()))
         dtype = _PRECISIONS[self.precision]
+        cast = self.conv1.weight.dtype
         if _records_graph(self, x):
+            _need_fp32_parameters(cast)
             if dtype != DTYPE_BF16:        # exact-fp32 training: one autograd node per conv
                 return fp32_train.block_forward(self, x.float(), False)
             return _BlockFunction.apply(x.float().contiguous(), self, *[p for c in self._convs() for p in (c.weight, c.bias)])
         cpu = ops.UNIT_CHANNELS[dtype]
         units = (self.in_channels + 4 * self.growth_channels) // cpu
+        x = x.float()
         buf = ops.to_blocked(x, units, dtype)
         nxt = torch.empty_like(buf)
         trunk = ops.to_blocked(x, self.in_channels // 4, DTYPE_F32)
         self._run(buf, trunk, trunk, nxt, dtype)
-        return ops.from_blocked(trunk, 0, self.in_channels)
+        out = ops.from_blocked(trunk, 0, self.in_channels)
+        return out if cast == torch.float32 else out.to(cast)
 
 
 class RRDB(nn.Module):
@@ -200,13 +205,16 @@ class RRDB(nn.Module):
         if x.shape[0] == 0:
             return _empty_result(x, self.in_channels, 1, list(self.parameters()))
         dtype = _PRECISIONS[self.precision]
+        cast = self.rdb1.conv1.weight.dtype
         if _records_graph(self, x):
+            _need_fp32_parameters(cast)
             if dtype != DTYPE_BF16:
                 return fp32_train.block_forward(self, x.float(), True)
             params = [p for r in (self.rdb1, self.rdb2, self.rdb3) for c in r._convs() for p in (c.weight, c.bias)]
             return _BlockFunction.apply(x.float().contiguous(), self, *params)
         cpu = ops.UNIT_CHANNELS[dtype]
         units = (self.in_channels + 4 * self.growth_channels) // cpu
+        x = x.float()
         cur = ops.to_blocked(x, units, dtype)
         nxt = torch.empty_like(cur)
         outer = ops.to_blocked(x, self.in_channels // 4, DTYPE_F32)   # fp32 RRDB input
@@ -214,7 +222,8 @@ class RRDB(nn.Module):
         self.rdb1._run(cur, outer, trunk, nxt, dtype)
         self.rdb2._run(nxt, trunk, trunk, cur, dtype)
         self.rdb3._run(cur, trunk, None, nxt, dtype, outer=outer, outer_out=outer)
-        return ops.from_blocked(outer, 0, self.in_channels)
+        out = ops.from_blocked(outer, 0, self.in_channels)
+        return out if cast == torch.float32 else out.to(cast)
 
 
 class GeneratorRRDB(nn.Module):
@@ -316,7 +325,10 @@ class GeneratorRRDB(nn.Module):
         params = self.conv_parameters()
         cfg = self.cfg(inference)
         cache = self._cache_inf if cfg[6] == HR_F16 else self._cache
-        return cache.get(params, (cfg[5], cfg[6]), lambda: ops.generator_pack_now(params[0::2], params[1::2], cfg),
+        # (a module cast by .half() / .bfloat16() / .double() packs from fp32 copies of its parameters)
+        return cache.get(params, (cfg[5], cfg[6]),
+                         lambda: ops.generator_pack_now([w.detach().float() for w in params[0::2]],
+                                                        [b.detach().float() for b in params[1::2]], cfg),
                          not _is_replica(self))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:
@@ -346,15 +358,18 @@ class GeneratorRRDB(nn.Module):
             return _empty_result(x, self.out_channels, 4, list(self.parameters()))
         xin = x.float().contiguous()
         params = self.conv_parameters()
+        cast = params[0].dtype          # a cast module (netG.half()) returns its own dtype, as nn.Conv2d does
         if torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in params)):
+            _need_fp32_parameters(cast)
             if _PRECISIONS[self.precision] != DTYPE_BF16:
                 # exact-fp32 training (the reference without autocast): one autograd node per conv, gradients
                 # through autograd's own accumulation
                 return fp32_train.generator_forward(self, xin)
             return _GeneratorFunction.apply(xin, self, None, *_graph_params(self, params))
         N, _c, H, W = xin.shape
-        return self._checked(xin.device, lambda: ops.generator_forward(
+        out = self._checked(xin.device, lambda: ops.generator_forward(
             xin.detach(), self.packed_parameters(True), self.workspace(N, H, W, xin.device), self.cfg(True)))
+        return out if cast == torch.float32 else out.to(cast)
 
     def _checked(self, device, run):
         """``run()``; with ``checked`` also wait for the body's persistent launch and, if it gave up, run again (the
@@ -425,6 +440,7 @@ class _GeneratorFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_out: Tensor):
         module, cfg = ctx.module, ctx.module.cfg()
         N, H, W = ctx.lr_shape
@@ -486,6 +502,13 @@ def _check_input(x: Tensor, channels: int) -> None:
                            f"({x.shape[2] + 2} x {x.shape[3] + 2})")
 
 
+def _need_fp32_parameters(dtype) -> None:
+    if dtype != torch.float32:
+        raise RuntimeError(f"a recorded forward needs fp32 parameters (the backward writes fp32 gradients), got {dtype}: "
+                           "keep the module in fp32 -- the kernels compute in bf16 either way -- or call it under "
+                           "torch.no_grad()")
+
+
 def _empty_result(x: Tensor, channels: int, scale: int, params) -> Tensor:
     """What the reference's convs return for a batch of no images: ``[0, channels, scale H, scale W]``, connected to the
     graph (all-zero gradients) where one is recorded."""
@@ -529,6 +552,7 @@ class _BlockFunction(torch.autograd.Function):
         return ops.from_blocked(out, 0, nf)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         g = g.float().contiguous()
         blocks, bufs = ctx.blocks, ctx.bufs

@@ -15,6 +15,7 @@ from typing import Optional
 
 import torch
 from torch import Tensor
+from torch.autograd.function import once_differentiable
 
 from . import ops
 from ._lib import DTYPE_F32
@@ -38,6 +39,7 @@ class _ToBlockedF32(torch.autograd.Function):
         return ops.to_blocked_now(x.detach().float().contiguous(), _units4(x.shape[1]), DTYPE_F32)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         return ops.from_blocked_now(g.contiguous(), 0, ctx.channels)
 
@@ -49,6 +51,7 @@ class _FromBlockedF32(torch.autograd.Function):
         return ops.from_blocked_now(buf.detach().contiguous(), 0, channels)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g: Tensor):
         return ops.to_blocked_now(g.float().contiguous(), ctx.units, DTYPE_F32), None
 
@@ -82,6 +85,7 @@ class _ConvF32(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy: Tensor):
         x, weight, y = ctx.saved_tensors
         cout, cin = int(weight.shape[0]), int(weight.shape[1])

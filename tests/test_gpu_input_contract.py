@@ -106,3 +106,51 @@ def test_discriminator_and_vgg_input_contract():
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         D.forward_pair(torch.rand(1, 3, 16, 16, device=DEV), torch.rand(1, 3, 16, 16, device=DEV))
     assert D(torch.rand(2, 3, 16, 16, device=DEV)).shape == (2, 1, 1, 1)
+
+
+def test_module_level_operations(net):
+    """deepcopy, pickling, a round trip over the CPU, casts and partial freezing, as nn.Module users apply them."""
+    import copy
+    import io
+    x = torch.rand(2, 3, 12, 20, device=DEV)
+    with torch.no_grad():
+        ref = net(x)
+        assert torch.equal(copy.deepcopy(net)(x), ref)
+        buf = io.BytesIO()
+        torch.save(net, buf)
+        buf.seek(0)
+        assert torch.equal(torch.load(buf, weights_only=False)(x), ref)      # (a file this test wrote itself)
+        moved = copy.deepcopy(net).cpu()
+        with pytest.raises(RuntimeError, match="ROCm"):
+            moved(x.cpu())
+        assert torch.equal(moved.to(DEV)(x), ref)
+        # a cast module computes as before (bf16 kernels on fp32 copies of its parameters) and answers in its dtype
+        for cast, tol in ((torch.float16, 2e-3), (torch.bfloat16, 2e-2), (torch.float64, 0.0)):
+            m = copy.deepcopy(net).to(cast)
+            out = m(x.to(cast))
+            assert out.dtype == cast
+            assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), cast
+            blk = copy.deepcopy(net.body[0]).to(cast)
+            assert blk(torch.randn(1, 64, 6, 7, device=DEV, dtype=cast)).dtype == cast
+    with pytest.raises(RuntimeError, match="fp32 parameters"):
+        copy.deepcopy(net).half().train()(x.half())
+    # frozen parameters get no gradient, the others the same gradients as without the freeze
+    a, b = copy.deepcopy(net).train(), copy.deepcopy(net).train()
+    a.conv_first.requires_grad_(False)
+    a.body[0].rdb2.conv3.weight.requires_grad_(False)
+    a(x).square().mean().backward()
+    b(x).square().mean().backward()
+    frozen = [p.grad is None for p in a.parameters()]
+    assert sum(frozen) == 3
+    assert all(torch.equal(p.grad, q.grad) for p, q in zip(a.parameters(), b.parameters()) if p.grad is not None)
+
+
+def test_second_order_gradients_are_refused_not_wrong(net):
+    """The backward kernels are not differentiable a second time: asking for it raises instead of returning a graph that
+    ignores them."""
+    import copy
+    m = copy.deepcopy(net).train()
+    x = torch.rand(1, 3, 8, 8, device=DEV, requires_grad=True)
+    g, = torch.autograd.grad(m(x).square().mean(), x, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|twice"):
+        g.square().sum().backward()
