@@ -58,6 +58,13 @@ class _FromBlocked(torch.autograd.Function):
 
 def to_blocked(x: Tensor) -> Tensor:
     """NCHW fp32 -> blocked bf16 [N, H, units, W, 8] (differentiable)."""
+    if x.dim() != 4 or not x.is_floating_point():
+        # (nn.Conv2d refuses integer images the same way)
+        raise RuntimeError(f"conv core: expected a floating-point NCHW tensor; Input type ({x.dtype}, shape "
+                           f"{tuple(x.shape)}) and weight type (torch.float32) should be the same")
+    if 0 in x.shape:
+        raise RuntimeError(f"conv core: a tensor without elements {tuple(x.shape)} (an empty batch or image) has no "
+                           "blocked form; skip the call for an empty batch")
     return _ToBlocked.apply(x)
 
 

@@ -23,6 +23,9 @@ def _need_cuda(x: Tensor) -> None:
     if not x.is_cuda:
         raise RuntimeError("super_resolution_amd.cvae.CVAE runs on ROCm devices only: move the module and its input to "
                            "'cuda' (there is no CPU fallback)")
+    if not x.is_floating_point():
+        # (the reference's first nn.Conv2d refuses integer images the same way)
+        raise RuntimeError(f"CVAE: Input type ({x.dtype}) and weight type (torch.float32) should be the same")
 
 
 def _conv_f32(x_nchw: Tensor, conv: nn.Conv2d) -> Tensor:

@@ -19,6 +19,10 @@ def _need_cuda(x: Tensor, who: str) -> None:
     if not x.is_cuda:
         raise RuntimeError(f"super_resolution_amd.{who} runs on ROCm devices only: move the module and its input to "
                            "'cuda' (there is no CPU fallback)")
+    if x.dim() != 4 or not x.is_floating_point():
+        # (the reference's first nn.Conv2d refuses integer images the same way)
+        raise RuntimeError(f"{who}: expected a floating-point NCHW tensor; Input type ({x.dtype}, shape {tuple(x.shape)}) "
+                           "and weight type (torch.float32) should be the same")
 
 
 def _nchw_to_f32(v: Tensor) -> Tensor:

@@ -399,6 +399,10 @@ class GeneratorRRDB(nn.Module):
             raise RuntimeError("super_resolution_amd runs on ROCm devices only: move the image to 'cuda' "
                                "(there is no CPU fallback)")
         N, H, W, _c = img.shape
+        if N == 0:
+            return img.new_zeros((0, 4 * H, 4 * W, self.out_channels))
+        if H == 0 or W == 0:
+            raise RuntimeError(f"an image without pixels: {tuple(image.shape)}")
         out = self._checked(img.device, lambda: ops.generator_forward_u8(
             img.contiguous(), self.packed_parameters(True), self.workspace(N, H, W, img.device), self.cfg(True)))
         return out[0] if single else out

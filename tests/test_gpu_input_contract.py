@@ -154,3 +154,43 @@ def test_second_order_gradients_are_refused_not_wrong(net):
     g, = torch.autograd.grad(m(x).square().mean(), x, create_graph=True)
     with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|twice"):
         g.square().sum().backward()
+
+
+def test_byte_edge_and_tiling_on_unusual_inputs(net):
+    from super_resolution_amd import sharded
+    img = (torch.rand(13, 17, 3, device=DEV) * 255).to(torch.uint8)
+    ref = net.upscale_u8(img)
+    assert torch.equal(net.upscale_u8(img.permute(2, 0, 1).contiguous().permute(1, 2, 0)), ref)    # a strided HWC view
+    assert torch.equal(net.upscale_u8(img[None].repeat(3, 1, 1, 1))[2], ref)
+    assert net.upscale_u8(img[:1, :1]).shape == (4, 4, 3)
+    assert net.upscale_u8(img[None][:0]).shape == (0, 52, 68, 3)
+    for bad in (img.float(), img.permute(2, 0, 1), img[:0]):
+        with pytest.raises(RuntimeError):
+            net.upscale_u8(bad)
+    exact = S.GeneratorRRDB(num_blocks=1, precision="fp32")
+    exact.load_state_dict(net.state_dict())
+    exact = exact.to(DEV).eval()
+    with torch.no_grad():
+        for shape, tiles in (((1, 3, 5, 7), 4), ((1, 3, 40, 33), 1), ((2, 3, 40, 33), 6), ((1, 3, 40, 33), 64)):
+            x = torch.rand(*shape, device=DEV)
+            # (more tiles than the halo leaves room for: every window is the whole image)
+            assert (sharded.tiled_forward(exact, x, tiles) - exact(x)).abs().max().item() < 1e-5, (shape, tiles)
+        for tiles, halo in ((0, 8), (2, -1)):
+            with pytest.raises(ValueError):
+                sharded.tiled_forward(exact, torch.rand(1, 3, 8, 8, device=DEV), tiles, halo)
+        with pytest.raises(ValueError, match="cannot be cut"):
+            sharded.tiled_forward(exact, torch.rand(1, 3, 1, 1, device=DEV), 4)
+
+
+def test_widened_models_refuse_what_their_first_conv_refuses():
+    from super_resolution_amd import cvae, cyclegan
+    G, Dn, M = cyclegan.GeneratorSR().to(DEV).eval(), cyclegan.GeneratorDown().to(DEV).eval(), cvae.CVAE().to(DEV).eval()
+    bytes_ = torch.zeros(1, 3, 32, 32, dtype=torch.uint8, device=DEV)
+    with torch.no_grad():
+        for m in (G, Dn, M):
+            with pytest.raises(RuntimeError, match="should be the same"):
+                m(bytes_)
+        assert G(torch.rand(2, 3, 9, 11, device=DEV)).shape == (2, 3, 36, 44)
+        assert Dn(torch.rand(1, 3, 37, 45, device=DEV)).shape == (1, 3, 9, 11)
+        with pytest.raises(RuntimeError, match="empty batch"):
+            G(torch.rand(0, 3, 9, 11, device=DEV))
