@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 16
+#define SR355_ABI_VERSION 17
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -283,6 +283,24 @@ int sr355_bn_lrelu_bwd(const float *x_f32_dev, size_t x_bytes, const void *dy_ac
                        const float *save_mean_dev, const float *save_rstd_dev, float lrelu_slope, int training,
                        void *dx_act_dev, size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma_dev,
                        float *dbeta_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+/* The same two passes for a batch that stands for `groups` separate calls of the layer on its `groups` consecutive
+ * sub-batches of N / groups images (the discriminator update of /root/reference/esrgan/train.py:200-201 calls the
+ * network on the real and on the generated batch: run as one batch, every normalised layer still has to take its
+ * statistics per call): statistics, save_mean / save_rstd and dgamma / dbeta are [groups][C], the running buffers are
+ * updated once per group in order, and the results are bit-identical to `groups` calls of the entry points above on
+ * the slices -- in one set of launches.  workspace: groups * sr355_bn_workspace_bytes(N / groups, H, W, C). */
+int sr355_bn_lrelu_fwd_groups(const float *x_f32_dev, size_t x_bytes, int N, int H, int W, int C, const float *gamma_dev,
+                              const float *beta_dev, float eps, float lrelu_slope, int training, float momentum,
+                              float *running_mean_dev, float *running_var_dev, long long *num_batches_tracked_dev,
+                              float *save_mean_dev, float *save_rstd_dev, void *out_act_dev, size_t out_act_bytes,
+                              int out_units, int out_unit_off, void *workspace_dev, size_t workspace_bytes, int groups,
+                              void *stream);
+int sr355_bn_lrelu_bwd_groups(const float *x_f32_dev, size_t x_bytes, const void *dy_act_dev, size_t dy_bytes,
+                              int dy_units, int dy_unit_off, int N, int H, int W, int C, const float *gamma_dev,
+                              const float *beta_dev, const float *save_mean_dev, const float *save_rstd_dev,
+                              float lrelu_slope, int training, void *dx_act_dev, size_t dx_bytes, int dx_units,
+                              int dx_unit_off, float *dgamma_dev, float *dbeta_dev, void *workspace_dev,
+                              size_t workspace_bytes, int groups, void *stream);
 
 /* nn.PixelShuffle(2) on the blocked layout (the sub-pixel stages of CycleGAN/CycleGAN_w_v1/CycleGAN.py:117-129,
  * condtional VAE/model.py:118-133): src [N][H][4*c_out/c][W][c] -> dst [N][2H][c_out/c][2W][c],

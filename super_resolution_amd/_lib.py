@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -40,7 +40,8 @@ EXPORTS = (
     "sr355_generator_grads_floats", "sr355_generator_backward",
     "sr355_generator_backward_phases", "sr355_generator_backward_range",
     "sr355_adam_step",
-    "sr355_bn_workspace_bytes", "sr355_bn_lrelu_fwd", "sr355_bn_lrelu_bwd",
+    "sr355_bn_workspace_bytes", "sr355_bn_lrelu_fwd", "sr355_bn_lrelu_bwd", "sr355_bn_lrelu_fwd_groups",
+    "sr355_bn_lrelu_bwd_groups",
     "sr355_pixel_shuffle2", "sr355_maxpool2x2_fwd", "sr355_maxpool2x2_bwd", "sr355_loss_workspace_bytes", "sr355_loss_fwd",
 )
 
@@ -208,6 +209,9 @@ def lib() -> C.CDLL:
     L.sr355_bn_workspace_bytes.restype = sz
     L.sr355_bn_lrelu_fwd.argtypes = [vp, sz, i, i, i, i, vp, vp, f, f, i, f, vp, vp, vp, vp, vp, vp, sz, i, i, vp, sz, vp]
     L.sr355_bn_lrelu_bwd.argtypes = [vp, sz, vp, sz, i, i, i, i, i, i, vp, vp, vp, vp, f, i, vp, sz, i, i, vp, vp, vp, sz, vp]
+    L.sr355_bn_lrelu_fwd_groups.argtypes = [vp, sz, i, i, i, i, vp, vp, f, f, i, f, vp, vp, vp, vp, vp, vp, sz, i, i, vp, sz, i, vp]
+    L.sr355_bn_lrelu_bwd_groups.argtypes = [vp, sz, vp, sz, i, i, i, i, i, i, vp, vp, vp, vp, f, i, vp, sz, i, i, vp, vp, vp, sz,
+                                            i, vp]
     L.sr355_maxpool2x2_fwd.argtypes = [vp, sz, i, i, i, i, vp, sz, vp]
     L.sr355_pixel_shuffle2.argtypes = [vp, sz, i, i, i, i, i, i, vp, sz, vp]
     L.sr355_maxpool2x2_bwd.argtypes = [vp, sz, vp, sz, i, i, i, i, vp, sz, vp]

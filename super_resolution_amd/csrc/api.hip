@@ -663,9 +663,13 @@ size_t sr355_bn_workspace_bytes(int N, int H, int W, int C) {
 
 static int bn_checks(const char *who, const float *x, size_t x_bytes, int N, int H, int W, int C, const float *gamma,
                      const float *beta, const float *mean, const float *rstd, const void *act, size_t act_bytes,
-                     int units, int unit_off, const void *ws, size_t ws_bytes) {
+                     int units, int unit_off, const void *ws, size_t ws_bytes, int groups = 1) {
     if (N < 1 || H < 1 || W < 1 || C < 8 || (C & 7)) {
         set_error("%s: bad shape N=%d H=%d W=%d C=%d (channels in whole 8-channel units)", who, N, H, W, C);
+        return SR355_ERR_INVALID;
+    }
+    if (groups < 1 || N % groups) {
+        set_error("%s: %d groups do not divide the batch of %d", who, groups, N);
         return SR355_ERR_INVALID;
     }
     const size_t px = (size_t)N * H * W;
@@ -677,8 +681,9 @@ static int bn_checks(const char *who, const float *x, size_t x_bytes, int N, int
         set_error("%s: blocked tensor geometry invalid (off=%d units=%d, %zu bytes)", who, unit_off, units, act_bytes);
         return SR355_ERR_INVALID;
     }
-    if (!ws || !aligned16(ws) || ws_bytes < sr355_bn_workspace_bytes(N, H, W, C)) {
-        set_error("%s: workspace missing or smaller than %zu bytes", who, sr355_bn_workspace_bytes(N, H, W, C));
+    const size_t ws_need = (size_t)groups * sr355_bn_workspace_bytes(N / groups, H, W, C);
+    if (!ws || !aligned16(ws) || ws_bytes < ws_need) {
+        set_error("%s: workspace missing or smaller than %zu bytes", who, ws_need);
         return SR355_ERR_INVALID;
     }
     return SR355_OK;
@@ -689,8 +694,18 @@ int sr355_bn_lrelu_fwd(const float *x_f32, size_t x_bytes, int N, int H, int W, 
                        float *running_mean, float *running_var, long long *num_batches_tracked, float *save_mean,
                        float *save_rstd, void *out_act, size_t out_act_bytes, int out_units, int out_unit_off,
                        void *workspace, size_t workspace_bytes, void *stream) {
+    return sr355_bn_lrelu_fwd_groups(x_f32, x_bytes, N, H, W, C, gamma, beta, eps, lrelu_slope, training, momentum,
+                                     running_mean, running_var, num_batches_tracked, save_mean, save_rstd, out_act,
+                                     out_act_bytes, out_units, out_unit_off, workspace, workspace_bytes, 1, stream);
+}
+
+int sr355_bn_lrelu_fwd_groups(const float *x_f32, size_t x_bytes, int N, int H, int W, int C, const float *gamma,
+                              const float *beta, float eps, float lrelu_slope, int training, float momentum,
+                              float *running_mean, float *running_var, long long *num_batches_tracked, float *save_mean,
+                              float *save_rstd, void *out_act, size_t out_act_bytes, int out_units, int out_unit_off,
+                              void *workspace, size_t workspace_bytes, int groups, void *stream) {
     const int rc = bn_checks("bn_lrelu_fwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd, out_act,
-                             out_act_bytes, out_units, out_unit_off, workspace, workspace_bytes);
+                             out_act_bytes, out_units, out_unit_off, workspace, workspace_bytes, groups);
     if (rc) return rc;
     if (!training && (!running_mean || !running_var)) {
         set_error("bn_lrelu_fwd: eval mode needs the running statistics");
@@ -698,7 +713,7 @@ int sr355_bn_lrelu_fwd(const float *x_f32, size_t x_bytes, int N, int H, int W, 
     }
     return launch_bn_lrelu_fwd(x_f32, N, H, W, C, gamma, beta, eps, lrelu_slope, training, momentum, running_mean,
                                running_var, num_batches_tracked, save_mean, save_rstd, out_act, out_units, out_unit_off,
-                               (float *)workspace, (hipStream_t)stream);
+                               (float *)workspace, (hipStream_t)stream, groups);
 }
 
 int sr355_bn_lrelu_bwd(const float *x_f32, size_t x_bytes, const void *dy_act, size_t dy_bytes, int dy_units,
@@ -706,11 +721,21 @@ int sr355_bn_lrelu_bwd(const float *x_f32, size_t x_bytes, const void *dy_act, s
                        const float *save_mean, const float *save_rstd, float lrelu_slope, int training, void *dx_act,
                        size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma, float *dbeta, void *workspace,
                        size_t workspace_bytes, void *stream) {
+    return sr355_bn_lrelu_bwd_groups(x_f32, x_bytes, dy_act, dy_bytes, dy_units, dy_unit_off, N, H, W, C, gamma, beta,
+                                     save_mean, save_rstd, lrelu_slope, training, dx_act, dx_bytes, dx_units, dx_unit_off,
+                                     dgamma, dbeta, workspace, workspace_bytes, 1, stream);
+}
+
+int sr355_bn_lrelu_bwd_groups(const float *x_f32, size_t x_bytes, const void *dy_act, size_t dy_bytes, int dy_units,
+                              int dy_unit_off, int N, int H, int W, int C, const float *gamma, const float *beta,
+                              const float *save_mean, const float *save_rstd, float lrelu_slope, int training,
+                              void *dx_act, size_t dx_bytes, int dx_units, int dx_unit_off, float *dgamma, float *dbeta,
+                              void *workspace, size_t workspace_bytes, int groups, void *stream) {
     // dy_units == 0: the gradient is an fp32 tensor in x's layout; the geometry check below then runs on dx's
     const bool dy_f32 = dy_units == 0;
     int rc = bn_checks("bn_lrelu_bwd", x_f32, x_bytes, N, H, W, C, gamma, beta, save_mean, save_rstd,
                        dy_f32 ? dx_act : dy_act, dy_f32 ? dx_bytes : dy_bytes, dy_f32 ? dx_units : dy_units,
-                       dy_f32 ? dx_unit_off : dy_unit_off, workspace, workspace_bytes);
+                       dy_f32 ? dx_unit_off : dy_unit_off, workspace, workspace_bytes, groups);
     if (rc) return rc;
     const size_t px = (size_t)N * H * W;
     if (dy_f32 && (!dy_act || !aligned16(dy_act) || dy_unit_off != 0 || dy_bytes < px * C * 4)) {
@@ -724,7 +749,7 @@ int sr355_bn_lrelu_bwd(const float *x_f32, size_t x_bytes, const void *dy_act, s
     }
     return launch_bn_lrelu_bwd(x_f32, dy_act, dy_units, dy_unit_off, N, H, W, C, gamma, beta, save_mean, save_rstd,
                                lrelu_slope, training, dx_act, dx_units, dx_unit_off, dgamma, dbeta, (float *)workspace,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, groups);
 }
 
 int sr355_maxpool2x2_fwd(const void *in_act, size_t in_bytes, int N, int H, int W, int units, void *out_act,

@@ -62,11 +62,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ int bn_part_rows(int rows, int parts, int p) { return (rows - p + parts - 1) / parts; }
 
 __global__ void bn_partial_stats_kernel(const float4 *__restrict__ x, int rows, int Q, int W, int parts,
-                                        float *__restrict__ pmean /* [parts][4Q] */, float *__restrict__ pm2) {
+                                        float *__restrict__ pmean /* [groups][parts][4Q] */, float *__restrict__ pm2) {
     __shared__ float red[16];
     const int cq = blockIdx.y, p = blockIdx.x;
+    // group blockIdx.z: `rows` consecutive rows of x with statistics of their own (the two halves of a batch that stand
+    // for two separate calls of the layer)
+    x += (size_t)blockIdx.z * rows * Q * W;
+    pmean += (size_t)blockIdx.z * parts * 4 * Q, pm2 += (size_t)blockIdx.z * parts * 4 * Q;
     const int items = bn_part_rows(rows, parts, p) * W;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
         const int r = i / W, px = i - r * W;
         const float4 v = x[((size_t)(p + r * parts) * Q + cq) * W + px];
@@ -76,6 +81,7 @@ __global__ void bn_partial_stats_kernel(const float4 *__restrict__ x, int rows, 
     const float inv = 1.0f / (float)items;
     const float mean[4] = {s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv};
     float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
         const int r = i / W, px = i - r * W;
         const float4 v = x[((size_t)(p + r * parts) * Q + cq) * W + px];
@@ -94,26 +100,35 @@ __global__ void bn_partial_stats_kernel(const float4 *__restrict__ x, int rows, 
 __global__ void bn_finalize_kernel(const float *__restrict__ pmean, const float *__restrict__ pm2, int parts, int C, int rows,
                                    int W, float m, float eps, float momentum, float *__restrict__ running_mean,
                                    float *__restrict__ running_var, long long *__restrict__ num_batches,
-                                   float *__restrict__ save_mean, float *__restrict__ save_rstd) {
+                                   float *__restrict__ save_mean, float *__restrict__ save_rstd, int groups) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c == 0 && lane == 0 && num_batches) *num_batches += 1;
+    if (c == 0 && lane == 0 && num_batches) *num_batches += groups;
     if (c >= C) return;
-    float n_k = 0.f, mean_k = 0.f, m2_k = 0.f;
-    if (lane < parts) {
-        n_k = (float)(bn_part_rows(rows, parts, lane) * W);
-        mean_k = pmean[(size_t)lane * C + c];
-        m2_k = pm2[(size_t)lane * C + c];
+    // the groups in order: each is one call of the layer as far as the running buffers are concerned
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const float *pm = pmean + (size_t)g * parts * C, *pq = pm2 + (size_t)g * parts * C;
+        float n_k = 0.f, mean_k = 0.f, m2_k = 0.f;
+        if (lane < parts) {
+            n_k = (float)(bn_part_rows(rows, parts, lane) * W);
+            mean_k = pm[(size_t)lane * C + c];
+            m2_k = pq[(size_t)lane * C + c];
+        }
+        const float mean = wave_sum(n_k * mean_k) / m;
+        const float dlt = mean_k - mean;
+        const float q = wave_sum(m2_k + n_k * dlt * dlt);
+        const float var = q / m;
+        if (lane == 0) {
+            save_mean[(size_t)g * C + c] = mean;
+            save_rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
+        }
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rv = (1.f - momentum) * rv + momentum * (m > 1.f ? q / (m - 1.f) : var);
     }
-    const float mean = wave_sum(n_k * mean_k) / m;
-    const float dlt = mean_k - mean;
-    const float q = wave_sum(m2_k + n_k * dlt * dlt);
     if (lane) return;
-    const float var = q / m;
-    save_mean[c] = mean;
-    save_rstd[c] = 1.0f / sqrtf(var + eps);
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m > 1.f ? q / (m - 1.f) : var);
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
 }
 
 // eval mode: the statistics are the running buffers
@@ -130,12 +145,13 @@ __global__ void bn_eval_stats_kernel(const float *__restrict__ running_mean, con
 __global__ void bn_lrelu_apply_kernel(const float4 *__restrict__ x, size_t n_items, int U, int W,
                                       const float *__restrict__ mean, const float *__restrict__ rstd,
                                       const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-                                      __bf16 *__restrict__ out, int out_units, int out_unit_off) {
+                                      __bf16 *__restrict__ out, int out_units, int out_unit_off, int group_rows) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_items; i += (size_t)gridDim.x * blockDim.x) {
         const int px = (int)(i % W);
         const size_t t = i / W;
         const int u = (int)(t % U);
         const size_t row = t / U;
+        const int gs = (int)(row / (size_t)group_rows) * 8 * U;      // this row's group: its statistics start here
         __bf16 v[8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -144,7 +160,7 @@ __global__ void bn_lrelu_apply_kernel(const float4 *__restrict__ x, size_t n_ite
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = 8 * u + 4 * q + j;
-                const float z = gamma[c] * ((xs[j] - mean[c]) * rstd[c]) + beta[c];
+                const float z = gamma[c] * ((xs[j] - mean[gs + c]) * rstd[gs + c]) + beta[c];
                 v[4 * q + j] = (__bf16)(z > 0.f ? z : z * slope);
             }
         }
@@ -183,15 +199,18 @@ __global__ void bn_bwd_partial_kernel(const float4 *__restrict__ x, const void *
                                       const float *__restrict__ beta, float slope, float *__restrict__ pg,
                                       float *__restrict__ pgx) {
     __shared__ float red[16];
-    const int cq = blockIdx.y, p = blockIdx.x;
+    const int cq = blockIdx.y, p = blockIdx.x, grp = blockIdx.z;     // group: `rows` consecutive rows, own statistics
+    mean += (size_t)grp * 4 * Q, rstd += (size_t)grp * 4 * Q;
+    pg += (size_t)grp * parts * 4 * Q, pgx += (size_t)grp * parts * 4 * Q;
     float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mu[j] = mean[4 * cq + j], rs[j] = rstd[4 * cq + j], ga[j] = gamma[4 * cq + j], be[j] = beta[4 * cq + j];
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
     const int items = bn_part_rows(rows, parts, p) * W;
+#pragma unroll 2
     for (int i = threadIdx.x; i < items; i += AUX_THREADS) {
         const int r = i / W, px = i - r * W;
-        const size_t row = (size_t)(p + r * parts);
+        const size_t row = (size_t)grp * rows + (size_t)(p + r * parts);
         const float4 xv = x[(row * Q + cq) * W + px];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         float gv[4];
@@ -218,9 +237,11 @@ __global__ void bn_bwd_finalize_kernel(const float *__restrict__ pg, const float
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const size_t g = blockIdx.y;                                    // group
+    pg += g * parts * C, pgx += g * parts * C;
     const float s = wave_sum(lane < parts ? pg[(size_t)lane * C + c] : 0.f);
     const float q = wave_sum(lane < parts ? pgx[(size_t)lane * C + c] : 0.f);
-    if (lane == 0) dbeta[c] = s, dgamma[c] = q;
+    if (lane == 0) dbeta[g * C + c] = s, dgamma[g * C + c] = q;
 }
 
 // Backward, pass 2: dx = gamma * rstd * (g - dbeta / m - xhat * dgamma / m) in training mode (the batch statistics
@@ -231,12 +252,13 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const void *__
                                     const float *__restrict__ rstd, const float *__restrict__ gamma,
                                     const float *__restrict__ beta, const float *__restrict__ dbeta,
                                     const float *__restrict__ dgamma, float inv_m, float slope, int training,
-                                    __bf16 *__restrict__ dx, int dx_units, int dx_unit_off) {
+                                    __bf16 *__restrict__ dx, int dx_units, int dx_unit_off, int group_rows) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_items; i += (size_t)gridDim.x * blockDim.x) {
         const int px = (int)(i % W);
         const size_t t = i / W;
         const int u = (int)(t % U);
         const size_t row = t / U;
+        const int gs = (int)(row / (size_t)group_rows) * 8 * U;      // this row's group: statistics and sums start here
         float gv[8];
         __bf16 v[8];
         {
@@ -253,11 +275,11 @@ __global__ void bn_bwd_apply_kernel(const float4 *__restrict__ x, const void *__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = 8 * u + 4 * q + j;
-                const float xh = (xs[j] - mean[c]) * rstd[c];
+                const float xh = (xs[j] - mean[gs + c]) * rstd[gs + c];
                 const float z = gamma[c] * xh + beta[c];
                 float g = gv[4 * q + j] * (z > 0.f ? 1.f : slope);
-                if (training) g = g - dbeta[c] * inv_m - xh * dgamma[c] * inv_m;
-                v[4 * q + j] = (__bf16)(gamma[c] * rstd[c] * g);
+                if (training) g = g - dbeta[gs + c] * inv_m - xh * dgamma[gs + c] * inv_m;
+                v[4 * q + j] = (__bf16)(gamma[c] * rstd[gs + c] * g);
             }
         }
         uint4 pk;
@@ -397,52 +419,61 @@ size_t bn_workspace_floats(int N, int H, int W, int C) {
     return (size_t)2 * bn_parts(N * H) * C;
 }
 
+// `groups` (a divisor of N): the batch is that many consecutive sub-batches, each normalised with statistics of its own and
+// counted as one call by the running buffers, in order -- what `groups` calls on the slices of x do, in one set of launches.
+// save_mean / save_rstd (and dgamma / dbeta below) are [groups][C]; the workspace is `groups` times a sub-batch's.
 int launch_bn_lrelu_fwd(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, float eps,
                         float slope, int training, float momentum, float *running_mean, float *running_var,
                         long long *num_batches, float *save_mean, float *save_rstd, void *out_act, int out_units,
-                        int out_unit_off, float *workspace, hipStream_t stream) {
-    const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
-    const float m = (float)((double)N * H * W);
+                        int out_unit_off, float *workspace, hipStream_t stream, int groups) {
+    const int rows_g = (N / groups) * H, Q = C / 4, U = C / 8, parts = bn_parts(rows_g);
+    const float m = (float)((double)(N / groups) * H * W);
     if (training) {
-        float *pmean = workspace, *pm2 = workspace + (size_t)parts * C;
-        hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, rows,
-                           Q, W, parts, pmean, pm2);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, parts, C, rows, W, m,
-                           eps, momentum, running_mean, running_var, num_batches, save_mean, save_rstd);
+        float *pmean = workspace, *pm2 = workspace + (size_t)groups * parts * C;
+        hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(parts, Q, groups), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
+                           rows_g, Q, W, parts, pmean, pm2);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pmean, pm2, parts, C, rows_g, W, m,
+                           eps, momentum, running_mean, running_var, num_batches, save_mean, save_rstd, groups);
     } else {
-        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var, C,
-                           eps, save_mean, save_rstd);
+        // (eval mode: every group reads the running buffers)
+        for (int g = 0; g < groups; ++g)
+            hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, running_mean, running_var,
+                               C, eps, save_mean + (size_t)g * C, save_rstd + (size_t)g * C);
     }
-    const size_t n_items = (size_t)rows * U * W;
+    const size_t n_items = (size_t)N * H * U * W;
     hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream, (const float4 *)x,
-                       n_items, U, W, save_mean, save_rstd, gamma, beta, slope, (__bf16 *)out_act, out_units, out_unit_off);
+                       n_items, U, W, save_mean, save_rstd, gamma, beta, slope, (__bf16 *)out_act, out_units, out_unit_off,
+                       rows_g);
     return check_hip(hipGetLastError(), "bn_lrelu_fwd launch");
 }
 
 int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_unit_off, int N, int H, int W, int C,
                         const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
                         float slope, int training, void *dx, int dx_units, int dx_unit_off, float *dgamma, float *dbeta,
-                        float *workspace, hipStream_t stream) {
-    const int rows = N * H, Q = C / 4, U = C / 8, parts = bn_parts(rows);
-    const float m = (float)((double)N * H * W);
-    float *pg = workspace, *pgx = workspace + (size_t)parts * C;
+                        float *workspace, hipStream_t stream, int groups) {
+    const int rows_g = (N / groups) * H, Q = C / 4, U = C / 8, parts = bn_parts(rows_g);
+    const float m = (float)((double)(N / groups) * H * W);
+    float *pg = workspace, *pgx = workspace + (size_t)groups * parts * C;
     const bool dy_f32 = dy_units == 0;     // the gradient arrives as fp32 [N][H][C/4][W][4]
     if (dy_f32)
-        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, dy,
-                           dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope, pg, pgx);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(parts, Q, groups), dim3(AUX_THREADS), 0, stream,
+                           (const float4 *)x, dy, dy_units, dy_unit_off, rows_g, Q, W, parts, save_mean, save_rstd, gamma,
+                           beta, slope, pg, pgx);
     else
-        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(parts, Q), dim3(AUX_THREADS), 0, stream, (const float4 *)x, dy,
-                           dy_units, dy_unit_off, rows, Q, W, parts, save_mean, save_rstd, gamma, beta, slope, pg, pgx);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, pg, pgx, parts, C, dbeta, dgamma);
-    const size_t n_items = (size_t)rows * U * W;
+        hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(parts, Q, groups), dim3(AUX_THREADS), 0, stream,
+                           (const float4 *)x, dy, dy_units, dy_unit_off, rows_g, Q, W, parts, save_mean, save_rstd, gamma,
+                           beta, slope, pg, pgx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4, groups), dim3(256), 0, stream, pg, pgx, parts, C, dbeta,
+                       dgamma);
+    const size_t n_items = (size_t)N * H * U * W;
     if (dy_f32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream,
                            (const float4 *)x, dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta,
-                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
+                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off, rows_g);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(aux_grid(n_items)), dim3(AUX_THREADS), 0, stream,
                            (const float4 *)x, dy, dy_units, dy_unit_off, n_items, U, W, save_mean, save_rstd, gamma, beta,
-                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off);
+                           dbeta, dgamma, 1.0f / m, slope, training, (__bf16 *)dx, dx_units, dx_unit_off, rows_g);
     return check_hip(hipGetLastError(), "bn_lrelu_bwd launch");
 }
 

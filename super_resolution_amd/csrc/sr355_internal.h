@@ -226,11 +226,11 @@ size_t bn_workspace_floats(int N, int H, int W, int C);
 int launch_bn_lrelu_fwd(const float *x, int N, int H, int W, int C, const float *gamma, const float *beta, float eps,
                         float slope, int training, float momentum, float *running_mean, float *running_var,
                         long long *num_batches, float *save_mean, float *save_rstd, void *out_act, int out_units,
-                        int out_unit_off, float *workspace, hipStream_t stream);
+                        int out_unit_off, float *workspace, hipStream_t stream, int groups = 1);
 int launch_bn_lrelu_bwd(const float *x, const void *dy, int dy_units, int dy_unit_off, int N, int H, int W, int C,
                         const float *gamma, const float *beta, const float *save_mean, const float *save_rstd,
                         float slope, int training, void *dx, int dx_units, int dx_unit_off, float *dgamma, float *dbeta,
-                        float *workspace, hipStream_t stream);
+                        float *workspace, hipStream_t stream, int groups = 1);
 int launch_maxpool2x2_fwd(const void *in, int N, int H, int W, int U, void *out, hipStream_t stream);
 int launch_maxpool2x2_bwd(const void *in, const void *dy, int N, int H, int W, int U, void *dx, hipStream_t stream);
 int launch_pixel_shuffle2(const void *src, int N, int H, int W, int c_out, int dtype, int inverse, void *dst,

@@ -201,11 +201,10 @@ class _DiscriminatorFunction(torch.autograd.Function):
                 rstd = torch.empty((groups, cout), dtype=torch.float32, device=x.device)
                 act = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=x.device)
                 training = bool(bn.training)
-                for gi in range(groups):
-                    sl = slice(gi * part, (gi + 1) * part)
-                    ops.bn_lrelu_fwd_now(y32[sl], bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(slope),
-                                         training, float(bn.momentum), bn.running_mean, bn.running_var,
-                                         bn.num_batches_tracked, mean[gi], rstd[gi], act[sl], 0)
+                # (one set of launches for all groups: statistics per group, the running buffers updated group by group)
+                ops.bn_lrelu_fwd_now(y32, bn.weight.detach(), bn.bias.detach(), float(bn.eps), float(slope), training,
+                                     float(bn.momentum), bn.running_mean, bn.running_var, bn.num_batches_tracked, mean,
+                                     rstd, act, 0, groups)
                 saved.append((x, y32, mean, rstd, training))
                 x = act
         ctx.layers, ctx.saved, ctx.in_channels, ctx.groups, ctx.part = layers, saved, int(img.shape[1]), groups, part
@@ -250,10 +249,8 @@ class _DiscriminatorFunction(torch.autograd.Function):
                 dgamma = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
                 dbeta = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
                 g = g.contiguous()
-                for gi in range(groups):
-                    sl = slice(gi * part, (gi + 1) * part)
-                    ops.bn_lrelu_bwd_now(y32[sl], g[sl], bn.weight.detach(), bn.bias.detach(), mean[gi], rstd[gi],
-                                         float(slope), training, dyb[sl], dgamma[gi], dbeta[gi], 0, 0)
+                ops.bn_lrelu_bwd_now(y32, g, bn.weight.detach(), bn.bias.detach(), mean, rstd, float(slope), training,
+                                     dyb, dgamma, dbeta, 0, 0, groups)
                 dgamma = dgamma[0] if groups == 1 else dgamma.sum(0)
                 dbeta = dbeta[0] if groups == 1 else dbeta.sum(0)
             dx, dw, db = cc._conv_backward(x, w, b, dyb, stride, need_dx, need_dw, dx_f32=dx_f32, dy_split=dy_split)

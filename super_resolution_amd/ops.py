@@ -478,56 +478,71 @@ def conv3x3_wgrad_all(in_buf: Tensor, cin: int, dy: Tensor, cout: int, dw: Tenso
                                                                 "save_mean", "save_rstd", "out_act"))
 def bn_lrelu_fwd(x_f32: Tensor, gamma: Tensor, beta: Tensor, eps: float, slope: float, training: bool, momentum: float,
                  running_mean: Optional[Tensor], running_var: Optional[Tensor], num_batches_tracked: Optional[Tensor],
-                 save_mean: Tensor, save_rstd: Tensor, out_act: Tensor, out_unit_off: int = 0) -> None:
+                 save_mean: Tensor, save_rstd: Tensor, out_act: Tensor, out_unit_off: int = 0, groups: int = 1) -> None:
     """BatchNorm2d (batch statistics when ``training``) + LeakyReLU of an fp32 conv output ``[N, H, C/4, W, 4]`` into
-    blocked bf16 ``out_act``; updates the running buffers like nn.BatchNorm2d."""
+    blocked bf16 ``out_act``; updates the running buffers like nn.BatchNorm2d.  ``groups``: the batch stands for that
+    many calls of the layer on its consecutive sub-batches (statistics ``[groups, C]``, the running buffers updated once
+    per group in order), bit-identical to the separate calls."""
     _need_cuda(x_f32, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, out_act)
     N, H, Q, W, _c = (int(v) for v in x_f32.shape)
+    groups = int(groups)
+    if groups < 1 or N % groups or save_mean.numel() != groups * 4 * Q or save_rstd.numel() != groups * 4 * Q:
+        raise RuntimeError("bn_lrelu_fwd: the groups must divide the batch and the statistics be [groups, C]")
+    if not (x_f32.is_contiguous() and save_mean.is_contiguous() and save_rstd.is_contiguous()):
+        raise RuntimeError("bn_lrelu_fwd: contiguous tensors expected")
     L = _lib.lib()
-    need = L.sr355_bn_workspace_bytes(N, H, W, 4 * Q)
+    need = groups * L.sr355_bn_workspace_bytes(N // groups, H, W, 4 * Q)
     if need == 0:
         raise RuntimeError("bn_lrelu_fwd: channels must be a positive multiple of 8")
     ws = torch.empty(need, dtype=torch.uint8, device=x_f32.device)
     with _on(x_f32.device):
-        check(L.sr355_bn_lrelu_fwd(x_f32.data_ptr(), _nbytes(x_f32), N, H, W, 4 * Q, gamma.data_ptr(), beta.data_ptr(),
-                                   float(eps), float(slope), int(bool(training)), float(momentum), _ptr(running_mean),
-                                   _ptr(running_var), _ptr(num_batches_tracked), save_mean.data_ptr(),
-                                   save_rstd.data_ptr(), out_act.data_ptr(), _nbytes(out_act), int(out_act.shape[2]),
-                                   int(out_unit_off), ws.data_ptr(), need, _stream()), "sr355_bn_lrelu_fwd")
+        check(L.sr355_bn_lrelu_fwd_groups(x_f32.data_ptr(), _nbytes(x_f32), N, H, W, 4 * Q, gamma.data_ptr(),
+                                          beta.data_ptr(), float(eps), float(slope), int(bool(training)), float(momentum),
+                                          _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                                          save_mean.data_ptr(), save_rstd.data_ptr(), out_act.data_ptr(), _nbytes(out_act),
+                                          int(out_act.shape[2]), int(out_unit_off), ws.data_ptr(), need, groups, _stream()),
+              "sr355_bn_lrelu_fwd_groups")
 
 
 @bn_lrelu_fwd.register_fake
 def _(x_f32, gamma, beta, eps, slope, training, momentum, running_mean, running_var, num_batches_tracked, save_mean,
-      save_rstd, out_act, out_unit_off=0):
+      save_rstd, out_act, out_unit_off=0, groups=1):
     return None
 
 
 @torch.library.custom_op("sr355::bn_lrelu_bwd", mutates_args=("dx_act", "dgamma", "dbeta"))
 def bn_lrelu_bwd(x_f32: Tensor, dy_act: Tensor, gamma: Tensor, beta: Tensor, save_mean: Tensor, save_rstd: Tensor,
                  slope: float, training: bool, dx_act: Tensor, dgamma: Tensor, dbeta: Tensor, dy_unit_off: int = 0,
-                 dx_unit_off: int = 0) -> None:
-    """Backward of ``bn_lrelu_fwd``: the gradient of x as blocked bf16, and dgamma / dbeta.  ``dy_act`` is the blocked
-    bf16 gradient of the output or an fp32 tensor ``[N, H, C/4, W, 4]`` (a data-gradient conv's ``out_f32``)."""
+                 dx_unit_off: int = 0, groups: int = 1) -> None:
+    """Backward of ``bn_lrelu_fwd``: the gradient of x as blocked bf16, and dgamma / dbeta (``[groups, C]``: one row per
+    sub-batch, as the separate calls would return them).  ``dy_act`` is the blocked bf16 gradient of the output or an fp32
+    tensor ``[N, H, C/4, W, 4]`` (a data-gradient conv's ``out_f32``)."""
     _need_cuda(x_f32, dy_act, gamma, beta, save_mean, save_rstd, dx_act, dgamma, dbeta)
     N, H, Q, W, _c = (int(v) for v in x_f32.shape)
     dy_f32 = dy_act.dtype == torch.float32
     if dy_f32 and (tuple(dy_act.shape) != tuple(x_f32.shape) or dy_unit_off != 0 or not dy_act.is_contiguous()):
         raise RuntimeError("bn_lrelu_bwd: an fp32 gradient must be a contiguous tensor of x's shape [N, H, C/4, W, 4]")
+    groups = int(groups)
+    n_stat = groups * 4 * Q
+    if groups < 1 or N % groups or any(t.numel() != n_stat or not t.is_contiguous()
+                                       for t in (save_mean, save_rstd, dgamma, dbeta)):
+        raise RuntimeError("bn_lrelu_bwd: the groups must divide the batch and statistics / sums be contiguous [groups, C]")
     L = _lib.lib()
-    need = L.sr355_bn_workspace_bytes(N, H, W, 4 * Q)
+    need = groups * L.sr355_bn_workspace_bytes(N // groups, H, W, 4 * Q)
     ws = torch.empty(need, dtype=torch.uint8, device=x_f32.device)
     with _on(x_f32.device):
-        check(L.sr355_bn_lrelu_bwd(x_f32.data_ptr(), _nbytes(x_f32), dy_act.data_ptr(), _nbytes(dy_act),
-                                   0 if dy_f32 else int(dy_act.shape[2]), int(dy_unit_off), N, H, W, 4 * Q, gamma.data_ptr(),
-                                   beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), float(slope),
-                                   int(bool(training)), dx_act.data_ptr(), _nbytes(dx_act), int(dx_act.shape[2]),
-                                   int(dx_unit_off), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), need, _stream()),
-              "sr355_bn_lrelu_bwd")
+        check(L.sr355_bn_lrelu_bwd_groups(x_f32.data_ptr(), _nbytes(x_f32), dy_act.data_ptr(), _nbytes(dy_act),
+                                          0 if dy_f32 else int(dy_act.shape[2]), int(dy_unit_off), N, H, W, 4 * Q,
+                                          gamma.data_ptr(), beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(),
+                                          float(slope), int(bool(training)), dx_act.data_ptr(), _nbytes(dx_act),
+                                          int(dx_act.shape[2]), int(dx_unit_off), dgamma.data_ptr(), dbeta.data_ptr(),
+                                          ws.data_ptr(), need, groups, _stream()),
+              "sr355_bn_lrelu_bwd_groups")
 
 
 @bn_lrelu_bwd.register_fake
 def _(x_f32, dy_act, gamma, beta, save_mean, save_rstd, slope, training, dx_act, dgamma, dbeta, dy_unit_off=0,
-      dx_unit_off=0):
+      dx_unit_off=0, groups=1):
     return None
 
 

@@ -142,3 +142,45 @@ def test_mean_losses_and_their_gradients(n):
     l2 = cc.mse_loss(ag, 1.0)
     assert l1.item() == l2.item()
     assert abs(l1.item() - F.mse_loss(a.double(), torch.ones(n, dtype=torch.float64)).item()) < 1e-5 * max(1.0, l1.item())
+
+
+@pytest.mark.parametrize("case", [(4, 2, 64, 16, 16), (6, 3, 16, 5, 9), (2, 2, 512, 2, 2), (32, 2, 64, 64, 64), (8, 1, 32, 7, 3)])
+@pytest.mark.parametrize("dy_f32", [False, True])
+def test_grouped_batchnorm_is_the_separate_calls(case, dy_f32):
+    """``groups`` consecutive sub-batches in one set of launches: outputs, statistics, running buffers (updated group by
+    group) and every gradient bit-identical to one call per sub-batch (the discriminator update's two passes,
+    /root/reference/esrgan/train.py:200-201, run as one batch)."""
+    from super_resolution_amd import ops
+    N, groups, C, H, W = case
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = (torch.randn(N, H, C // 4, W, 4, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    part = N // groups
+
+    def run(grouped):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nb = torch.zeros((), dtype=torch.long, device=DEV)
+        mean, rstd = torch.empty(groups, C, device=DEV), torch.empty(groups, C, device=DEV)
+        out = torch.empty((N, H, C // 8, W, 8), dtype=torch.bfloat16, device=DEV)
+        if dy_f32:
+            dy = torch.randn(N, H, C // 4, W, 4, generator=torch.Generator().manual_seed(7)).to(DEV)
+        else:
+            dy = torch.randn(N, H, C // 8, W, 8, generator=torch.Generator().manual_seed(7)).to(DEV).bfloat16()
+        dx = torch.empty_like(out)
+        dgamma, dbeta = torch.empty(groups, C, device=DEV), torch.empty(groups, C, device=DEV)
+        if grouped:
+            ops.bn_lrelu_fwd(x, gamma, beta, 1e-5, 0.2, True, 0.1, rm, rv, nb, mean, rstd, out, 0, groups)
+            ops.bn_lrelu_bwd(x, dy, gamma, beta, mean, rstd, 0.2, True, dx, dgamma, dbeta, 0, 0, groups)
+        else:
+            for k in range(groups):
+                sl = slice(k * part, (k + 1) * part)
+                ops.bn_lrelu_fwd(x[sl], gamma, beta, 1e-5, 0.2, True, 0.1, rm, rv, nb, mean[k], rstd[k], out[sl], 0)
+                ops.bn_lrelu_bwd(x[sl], dy[sl], gamma, beta, mean[k], rstd[k], 0.2, True, dx[sl], dgamma[k], dbeta[k])
+        return out, mean, rstd, rm, rv, nb, dx, dgamma, dbeta
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="groups"):
+        mean = torch.empty(groups, C, device=DEV)
+        ops.bn_lrelu_fwd(x, gamma, beta, 1e-5, 0.2, True, 0.1, None, None, None, mean, mean.clone(),
+                         torch.empty((N, H, C // 8, W, 8), dtype=torch.bfloat16, device=DEV), 0, N + 1)
