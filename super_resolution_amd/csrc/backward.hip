@@ -29,6 +29,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ T cvt(float v);
 template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
@@ -210,24 +212,45 @@ struct WGeo {
 };
 }  // namespace
 
-// Two transposing reads = one MFMA operand: 8 consecutive pixels (rows of the LDS image) of the channel
-// this lane owns.  `p` is this lane's piece address (pixel q, channels 4p..4p+3) for the first 4 pixels.
-__device__ __forceinline__ bf16x8 read_tr_operand(const unsigned char *p) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * 16));
-    bf16x8 f;
-    __builtin_memcpy(&f, &lo, 8);
-    __builtin_memcpy(reinterpret_cast<char *>(&f) + 8, &hi, 8);
-    return f;
+// Two transposing reads = one MFMA operand: 8 consecutive pixels (rows of the LDS image) of the channel this lane
+// owns.  `addr` is this lane's piece address (pixel q, channels 4p..4p+3) for the first 4 pixels.
+// Issued through inline asm, and waited for by wg_frags_wait below: a transposing read the compiler can see is ordered
+// behind ALL LDS-DMA still in flight (it puts `s_waitcnt vmcnt(0)` in front of the first one), i.e. behind the tiles
+// this workgroup has just requested for its NEXT iterations, which turns the ring of tiles into one memory latency per
+// tile.  The kernel's own counted wait and barrier at the top of an iteration are what guarantee that the tile being
+// read has landed.
+struct WgFrag {
+    v2u_t lo, hi;
+};
+__device__ __forceinline__ void wg_frag_issue(WgFrag &f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:64"
+                 : "=&v"(f.lo), "=&v"(f.hi)
+                 : "v"(addr)
+                 : "memory");
+}
+__device__ __forceinline__ bf16x8 wg_frag_value(const WgFrag &f) {
+    const v4u_t raw = {f.lo.x, f.lo.y, f.hi.x, f.hi.y};
+    return __builtin_bit_cast(bf16x8, raw);
+}
+// Waits until at most `PENDING` LDS reads issued after these N fragments are outstanding (LDS reads return in order)
+// and ties the fragments' registers to the wait, so that nothing reads them earlier.
+template <int PENDING, int N>
+__device__ __forceinline__ void wg_frags_wait(WgFrag (&f)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].lo), "+v"(f[i].hi));
 }
 
-template <int MB>
+// WAVE = ky, a template argument: the three waves of a workgroup run three copies of the loop in which every "does this
+// wave's k-th DMA instruction belong to the gradient tile, the input tile or neither" is decided at compile time (as a
+// run-time value of the wave each was a scalar branch, some twenty per tile).
+template <int MB, int WAVE>
 __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     typedef WGeo<MB> G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = ky
+    constexpr int wave = WAVE;   // = ky
     const int chunk = blockIdx.y;
     // view of the arguments for this conv of a batched launch
     struct {
@@ -263,7 +286,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     // and the part of its offset that position contributes (cst).  Per tile there remain one add and two unsigned
     // compares per item, and the tile coordinates advance by the launch's stride without a division (a tile is
     // 24 MFMAs a wave: a set-up of a few hundred instructions per tile would be longer than the tile itself).
-    int voff[G::KMAX], ry[G::KMAX], rx[G::KMAX], cst[G::KMAX];
+    int ry[G::KMAX], rx[G::KMAX], cst[G::KMAX];
 #pragma unroll
     for (int k = 0; k < G::KMAX; ++k) {
         const int j = k * 3 + wave;
@@ -312,38 +335,43 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
         c_ty -= cy_ ? a.tiles_y : 0;                                                                    \
         c_n += d_n + cy_;                                                                               \
     }
-#define SR355_WG_SETUP()                                                                                \
+// Tile-level part of the addresses of the tile at the cursor (scalar values) ...
+    int y0_t = 0, x0_t = 0, base_dy_t = 0, base_in_t = 0;
+#define SR355_WG_BASES()                                                                                \
     {                                                                                                   \
         in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.in) + (size_t)c_n * in_img_bytes, 0, \
                                                     in_img_bytes, 0x00020000);                          \
         dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.dy) + (size_t)c_n * dy_img_bytes, 0, \
                                                     dy_img_bytes, 0x00020000);                          \
-        const int y0_ = c_ty * WTH, x0_ = c_tx * 32;   /* (multiples of 4 and 32: the shifts below split exactly) */ \
-        const int base_dy_ = (((y0_ >> a.dy_s2) * a.dy_units) * Wd + (x0_ >> a.dy_s2)) * 16;            \
-        const int base_in_ = (((y0_ >> a.ups) * a.in_units) * Win + (x0_ >> a.ups)) * 16;               \
-        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
-            const int j = k * 3 + wave;                                                                 \
-            const int base_ = j < G::DY_I ? base_dy_ : base_in_;                                        \
-            const bool ok_ = (unsigned)(y0_ + ry[k]) < (unsigned)H && (unsigned)(x0_ + rx[k]) < (unsigned)W && \
-                             !SR355_EXP_WG_NOLOAD_V;                                                    \
-            voff[k] = ok_ ? base_ + cst[k] : W_OOB;                                                     \
-        }                                                                                               \
+        y0_t = c_ty * WTH, x0_t = c_tx * 32;   /* (multiples of 4 and 32: the shifts below split exactly) */ \
+        base_dy_t = (((y0_t >> a.dy_s2) * a.dy_units) * Wd + (x0_t >> a.dy_s2)) * 16;                   \
+        base_in_t = (((y0_t >> a.ups) * a.in_units) * Win + (x0_t >> a.ups)) * 16;                      \
     }
-#define SR355_WG_ISSUE(SLOT)                                                                            \
+// ... and this wave's K-th DMA instruction of that tile into slot SLOT (LIVE false: the tile does not exist, the
+// instruction goes out with an out-of-range source and fills its piece of a free slot with zeros, so that every tile
+// costs every wave the same number of DMA instructions, which is what the counted waits rely on)
+#define SR355_WG_PIECE(K, SLOT, LIVE)                                                                   \
     {                                                                                                   \
-        unsigned char *dst = smem + (SLOT) * G::STAGE_BYTES;                                            \
-        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) {                                           \
-            const int j = k * 3 + wave;                                                                 \
-            if (j < G::JTOT) {                                                                          \
-                if (j < G::DY_I) {                                                                      \
-                    lds_void *l = (lds_void *)(dst + ((j >> 1) * DY_PITCH + (j & 1) * 64) * 16);        \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, l, 16, voff[k], 0, 0, 0);         \
-                } else {                                                                                \
-                    lds_void *l = (lds_void *)(dst + G::IN_OFF + (j - G::DY_I) * 1024);                 \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l, 16, voff[k], 0, 0, 0);         \
-                }                                                                                       \
+        const int j_ = (K) * 3 + wave;   /* (a constant once the loops around this are unrolled) */      \
+        if (j_ < G::JTOT) {                                                                             \
+            const int base_ = j_ < G::DY_I ? base_dy_t : base_in_t;                                     \
+            const bool ok_ = (LIVE) && (unsigned)(y0_t + ry[K]) < (unsigned)H &&                        \
+                             (unsigned)(x0_t + rx[K]) < (unsigned)W && !SR355_EXP_WG_NOLOAD_V;          \
+            const int vo_ = ok_ ? base_ + cst[K] : W_OOB;                                               \
+            unsigned char *dst_ = smem + (SLOT) * G::STAGE_BYTES;                                       \
+            if (j_ < G::DY_I) {                                                                         \
+                lds_void *l = (lds_void *)(dst_ + ((j_ >> 1) * DY_PITCH + (j_ & 1) * 64) * 16);         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, l, 16, vo_, 0, 0, 0);                 \
+            } else {                                                                                    \
+                lds_void *l = (lds_void *)(dst_ + G::IN_OFF + (j_ - G::DY_I) * 1024);                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, l, 16, vo_, 0, 0, 0);                 \
             }                                                                                           \
         }                                                                                               \
+    }
+#define SR355_WG_TILE(SLOT, LIVE)                                                                       \
+    {                                                                                                   \
+        SR355_WG_BASES();                                                                               \
+        _Pragma("unroll") for (int k = 0; k < G::KMAX; ++k) SR355_WG_PIECE(k, SLOT, LIVE);              \
     }
 
     f32x16 acc[3][MB];
@@ -380,55 +408,66 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     // waves), which is what the counted wait of the three-slot ring relies on.
     static_assert(MB != 1 || G::JTOT % 3 == 0, "counted waits need equal DMA counts per wave");
     const int n_my = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + nwg - 1) / nwg : 0;
-    if (n_my > 0) {
-        SR355_WG_SETUP();
-        SR355_WG_ISSUE(0);
-    }
     constexpr int AHEAD = G::N_STAGES - 1;
-    if (AHEAD > 1 && n_my > 1) {
+    // the first AHEAD tiles (requested with out-of-range sources where this workgroup has fewer)
+    SR355_WG_TILE(0, n_my > 0);
+    if (AHEAD > 1) {
         SR355_WG_ADVANCE();
-        SR355_WG_SETUP();
-        SR355_WG_ISSUE(1);
+        SR355_WG_TILE(1, n_my > 1);
     }
     int slot = 0;
     for (int it = 0; it < n_my; ++it) {
-        if (AHEAD == 2 && it + 1 < n_my)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::KMAX) : "memory");   // the next tile may still be in flight
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile `it` has landed once at most the AHEAD - 1 younger tiles' instructions of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * G::KMAX) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + AHEAD < n_my) {
-            const int slot2 = slot + AHEAD >= G::N_STAGES ? slot + AHEAD - G::N_STAGES : slot + AHEAD;
-            SR355_WG_ADVANCE();
-            SR355_WG_SETUP();
-            SR355_WG_ISSUE(slot2);
-        }
-        const unsigned char *buf = smem + slot * G::STAGE_BYTES;
+        // tile it + AHEAD goes into the slot tile it - 1 has just left; its DMA instructions are issued one or two a group
+        // below, in the shadow of that group's MFMAs
+        const bool live = it + AHEAD < n_my;
+        const int slot2 = slot + AHEAD >= G::N_STAGES ? slot + AHEAD - G::N_STAGES : slot + AHEAD;
+        SR355_WG_ADVANCE();
+        SR355_WG_BASES();
+        // eight groups (tile row y, 16-pixel half s) of MB + 3 fragments and 3 MB MFMAs; the fragments of group g + 1 are
+        // requested before the MFMAs of group g
+        const unsigned buf = (unsigned)(size_t)(smem + slot * G::STAGE_BYTES);
+        constexpr int NF = MB + 3, GROUPS = WTH * 2;
+        WgFrag fr[2][NF];
+#define SR355_WG_FRAGS(SET, GI)                                                                         \
+    {                                                                                                   \
+        const int y_ = (GI) >> 1, s_ = (GI) & 1;                                                        \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                               \
+            wg_frag_issue(fr[SET][mb], buf + dy_lane + (mb * 4 * DY_PITCH + y_ * 32 + 16 * s_) * 16);  \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                \
+            wg_frag_issue(fr[SET][MB + kx], buf + in_lane + (y_ * 34 + 16 * s_ + kx) * 16);            \
+    }
+        SR355_WG_FRAGS(0, 0);
 #pragma unroll
-        for (int y = 0; y < WTH; ++y) {
+        for (int gi = 0; gi < GROUPS; ++gi) {
+            const int cur = gi & 1;
+            if (gi + 1 < GROUPS) {
+                SR355_WG_FRAGS(cur ^ 1, gi + 1);
+                wg_frags_wait<2 * NF>(fr[cur]);      // the next group's reads (two instructions a fragment) may be pending
+            } else {
+                wg_frags_wait<0>(fr[cur]);
+            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 af[MB], bfr[3];
+            for (int k = gi; k < G::KMAX; k += GROUPS) SR355_WG_PIECE(k, slot2, live);
+            bf16x8 af[MB], bfr[3];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    af[mb] = read_tr_operand(buf + dy_lane + (mb * 4 * DY_PITCH + y * 32 + 16 * s) * 16);
-                }
+            for (int mb = 0; mb < MB; ++mb) af[mb] = wg_frag_value(fr[cur][mb]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    bfr[kx] = read_tr_operand(buf + in_lane + (y * 34 + 16 * s + kx) * 16);
-                }
+            for (int kx = 0; kx < 3; ++kx) bfr[kx] = wg_frag_value(fr[cur][MB + kx]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[kx][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[kx], acc[kx][mb], 0, 0, 0);
-                if (do_bias) {
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[kx][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[kx], acc[kx][mb], 0, 0, 0);
+            if (do_bias) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        accb[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], ones, accb[mb], 0, 0, 0);
-                }
+                for (int mb = 0; mb < MB; ++mb)
+                    accb[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], ones, accb[mb], 0, 0, 0);
             }
         }
+#undef SR355_WG_FRAGS
         slot = slot + 1 == G::N_STAGES ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -454,14 +493,25 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradArgs &a0) {
     }
 }
 
-#undef SR355_WG_SETUP
+#undef SR355_WG_BASES
+#undef SR355_WG_PIECE
+#undef SR355_WG_TILE
 #undef SR355_WG_ADVANCE
-#undef SR355_WG_ISSUE
 
 // Non-template entry points: hipcc (ROCm 7.2) emits no host stub for a kernel TEMPLATE whose body
 // issues LDS-DMA loads through two run-time selected descriptors; plain kernels are unaffected.
-__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb1(const WgradArgs a) { wgrad3x3_body<1>(a); }
-__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { wgrad3x3_body<2>(a); }
+template <int MB>
+__device__ __forceinline__ void wgrad3x3_waves(const WgradArgs &a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0)
+        wgrad3x3_body<MB, 0>(a);
+    else if (wave == 1)
+        wgrad3x3_body<MB, 1>(a);
+    else
+        wgrad3x3_body<MB, 2>(a);
+}
+__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb1(const WgradArgs a) { wgrad3x3_waves<1>(a); }
+__global__ __launch_bounds__(192) void wgrad3x3_kernel_mb2(const WgradArgs a) { wgrad3x3_waves<2>(a); }
 
 // dW[co][ci][tap] (=|+=) scale * sum_g slab[ci/32][g][tap][co][ci%32], and, when db is given,
 // db[co] (=|+=) scale * sum_g bias_slab[g][co]; a fixed summation order, so results are reproducible.
