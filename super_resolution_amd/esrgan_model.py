@@ -325,11 +325,13 @@ class GeneratorRRDB(nn.Module):
         params = self.conv_parameters()
         cfg = self.cfg(inference)
         cache = self._cache_inf if cfg[6] == HR_F16 else self._cache
-        # (a module cast by .half() / .bfloat16() / .double() packs from fp32 copies of its parameters)
-        return cache.get(params, (cfg[5], cfg[6]),
-                         lambda: ops.generator_pack_now([w.detach().float() for w in params[0::2]],
-                                                        [b.detach().float() for b in params[1::2]], cfg),
-                         not _is_replica(self))
+        def build():
+            if params[0].dtype == torch.float32:      # (no per-tensor calls on the usual path: 702 tensors a repack)
+                return ops.generator_pack_now(params[0::2], params[1::2], cfg)
+            # a module cast by .half() / .bfloat16() / .double() packs from fp32 copies of its parameters
+            return ops.generator_pack_now([w.detach().float() for w in params[0::2]],
+                                          [b.detach().float() for b in params[1::2]], cfg)
+        return cache.get(params, (cfg[5], cfg[6]), build, not _is_replica(self))
 
     def workspace(self, N: int, H: int, W: int, device) -> Tensor:
         """Scratch memory of a no-grad forward, kept per device and grown on demand."""
