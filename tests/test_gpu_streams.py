@@ -104,3 +104,42 @@ def test_adversarial_iteration_on_a_side_stream():
 
     a, b = run(False), run(True)
     assert len(a) == len(b) and all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+def test_two_host_threads_on_two_streams():
+    """Two threads, each with its own generator and stream, forward concurrently (persistent launches of one device are
+    ordered behind each other by the library; everything else may overlap): every result equals the single-threaded one."""
+    import threading
+    nets, xs, refs = [], [], []
+    for k in range(2):
+        sd = O.center_outputs(O.make_generator_state(51 + k, num_blocks=2))
+        net = S.GeneratorRRDB(num_blocks=2)
+        net.load_state_dict(sd)
+        nets.append(net.to(DEV).eval())
+        xs.append(torch.rand(4, 3, 128, 128 - 32 * k, device=DEV))
+    with torch.no_grad():
+        for net, x in zip(nets, xs):
+            refs.append(net(x))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device=DEV)
+            with torch.no_grad(), torch.cuda.stream(stream):
+                for _ in range(6):
+                    out = nets[k](xs[k])
+                    stream.synchronize()
+                    if not torch.equal(out, refs[k]):
+                        errors.append(f"thread {k}: result differs")
+        except Exception as exc:           # a worker's exception must fail the test, not vanish with the thread
+            errors.append(f"thread {k}: {type(exc).__name__}: {exc}")
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not any(t.is_alive() for t in threads), "a worker thread did not finish"
+    assert not errors, errors
+    S.ops.chain_status(True, torch.device(DEV))      # no persistent launch gave up
