@@ -396,6 +396,14 @@ def adversarial_step(sd_g: StateDict, sd_d: StateDict, sd_v: StateDict, lr_img: 
 # --------------------------------------------------------------------------
 # metrics used by the parity gates
 # --------------------------------------------------------------------------
+def _conv3(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, emulate_bf16: bool, stride: int = 1) -> torch.Tensor:
+    """A 3x3 / pad 1 conv of the widened models; ``emulate_bf16`` rounds input and weight to bf16 where the HIP conv core
+    does (the casts pass gradients through), so that a comparison of gradients is like for like."""
+    if emulate_bf16:
+        x, w = _bf16r(x), _bf16r(w)
+    return F.conv2d(x, w, b, stride=stride, padding=1)
+
+
 # ---- CycleGAN super-resolution generator (CycleGAN/CycleGAN_w_v1/CycleGAN.py:89-137; v2 is the same network) ----
 def generator_sr_layout(in_channels: int = 3, out_channels: int = 3, num_residual: int = 6,
                         base_channels: int = 64) -> List[Tuple[str, int, int, int]]:
@@ -421,19 +429,19 @@ def make_generator_sr_state(seed: int, **cfg) -> StateDict:
     return sd
 
 
-def generator_sr_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
+def generator_sr_forward(sd: StateDict, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
     """GeneratorSR.forward (CycleGAN.py:129-137): 7x7 conv + ReLU, residual blocks ``x + conv2(relu(conv1(x)))``
-    (:96-100), two (3x3 conv to 4x channels, PixelShuffle(2), ReLU) stages, 7x7 conv, tanh."""
-    F = torch.nn.functional
+    (:96-100), two (3x3 conv to 4x channels, PixelShuffle(2), ReLU) stages, 7x7 conv, tanh.  ``emulate_bf16``: the 3x3
+    convs round their operands as the HIP path does (the residual trunk stays fp32 there too)."""
     h = F.relu(F.conv2d(x, sd["conv1.0.weight"], sd["conv1.0.bias"], padding=3))
     i = 0
     while f"res_blocks.{i}.conv1.weight" in sd:
         p = f"res_blocks.{i}."
-        t = F.relu(F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
-        h = h + F.conv2d(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+        t = F.relu(_conv3(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], emulate_bf16))
+        h = h + _conv3(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], emulate_bf16)
         i += 1
     for up in ("up1.0", "up2.0"):
-        h = F.relu(F.pixel_shuffle(F.conv2d(h, sd[up + ".weight"], sd[up + ".bias"], padding=1), 2))
+        h = F.relu(F.pixel_shuffle(_conv3(h, sd[up + ".weight"], sd[up + ".bias"], emulate_bf16), 2))
     return torch.tanh(F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=3))
 
 
@@ -460,17 +468,17 @@ def make_generator_down_state(seed: int, **cfg) -> StateDict:
     return sd
 
 
-def generator_down_forward(sd: StateDict, x: torch.Tensor) -> torch.Tensor:
+def generator_down_forward(sd: StateDict, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
     """GeneratorDown.forward (CycleGAN.py:158-163): 7x7 conv + ReLU, two (4x4 / stride 2 conv, ReLU) stages, two
-    residual blocks, 7x7 conv, tanh."""
-    F = torch.nn.functional
+    residual blocks, 7x7 conv, tanh.  ``emulate_bf16``: the residual blocks' 3x3 convs round their operands as the HIP
+    path does."""
     h = F.relu(F.conv2d(x, sd["down.0.weight"], sd["down.0.bias"], padding=3))
     h = F.relu(F.conv2d(h, sd["down.2.weight"], sd["down.2.bias"], stride=2, padding=1))
     h = F.relu(F.conv2d(h, sd["down.4.weight"], sd["down.4.bias"], stride=2, padding=1))
     for i in range(2):
         p = f"res_blocks.{i}."
-        t = F.relu(F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1))
-        h = h + F.conv2d(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+        t = F.relu(_conv3(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], emulate_bf16))
+        h = h + _conv3(t, sd[p + "conv2.weight"], sd[p + "conv2.bias"], emulate_bf16)
     return torch.tanh(F.conv2d(h, sd["out_conv.weight"], sd["out_conv.bias"], padding=3))
 
 
@@ -529,12 +537,13 @@ def make_cvae_state(seed: int, latent_dim: int = 256) -> StateDict:
     return sd
 
 
-def cvae_encode(sd: StateDict, x: torch.Tensor, training: bool = False):
-    """CVAE.encode (model.py:150-163): (mu, logvar, (x1, x2, x3, x4))."""
-    x1 = F.leaky_relu(F.conv2d(x, sd["enc_conv1.0.weight"], sd["enc_conv1.0.bias"], padding=1), 0.2)
+def cvae_encode(sd: StateDict, x: torch.Tensor, training: bool = False, emulate_bf16: bool = False):
+    """CVAE.encode (model.py:150-163): (mu, logvar, (x1, x2, x3, x4)).  ``emulate_bf16``: the 3x3 convs round their
+    operands as the HIP path does."""
+    x1 = F.leaky_relu(_conv3(x, sd["enc_conv1.0.weight"], sd["enc_conv1.0.bias"], emulate_bf16), 0.2)
     feats, h = [x1], x1
     for k in (2, 3, 4):
-        h = F.conv2d(h, sd[f"enc_conv{k}.0.weight"], sd[f"enc_conv{k}.0.bias"], stride=2, padding=1)
+        h = _conv3(h, sd[f"enc_conv{k}.0.weight"], sd[f"enc_conv{k}.0.bias"], emulate_bf16, stride=2)
         h = F.leaky_relu(_bn(sd, f"enc_conv{k}.1", h, training), 0.2)
         feats.append(h)
     flat = h.flatten(1)
@@ -543,7 +552,8 @@ def cvae_encode(sd: StateDict, x: torch.Tensor, training: bool = False):
     return mu, logvar, tuple(feats)
 
 
-def cvae_decode(sd: StateDict, z: torch.Tensor, condition: torch.Tensor, skips, training: bool = False) -> torch.Tensor:
+def cvae_decode(sd: StateDict, z: torch.Tensor, condition: torch.Tensor, skips, training: bool = False,
+                emulate_bf16: bool = False) -> torch.Tensor:
     """CVAE.decode (model.py:170-204).  ``condition_processor`` (:99-104) is evaluated by the reference and its
     result never used; it is left out here."""
     skip1, skip2, skip3, _skip4 = skips
@@ -553,11 +563,11 @@ def cvae_decode(sd: StateDict, z: torch.Tensor, condition: torch.Tensor, skips, 
         h = F.leaky_relu(_bn(sd, f"dec_conv{k}.1", h, training), 0.2)
         h = torch.cat([h, skip], 1)
     for k in (1, 2):
-        h = F.pixel_shuffle(F.conv2d(h, sd[f"upsample{k}.0.weight"], sd[f"upsample{k}.0.bias"], padding=1), 2)
+        h = F.pixel_shuffle(_conv3(h, sd[f"upsample{k}.0.weight"], sd[f"upsample{k}.0.bias"], emulate_bf16), 2)
         h = F.leaky_relu(_bn(sd, f"upsample{k}.2", h, training), 0.2)
-    h = torch.tanh(F.conv2d(h, sd["final_conv.0.weight"], sd["final_conv.0.bias"], padding=1))
+    h = torch.tanh(_conv3(h, sd["final_conv.0.weight"], sd["final_conv.0.bias"], emulate_bf16))
     up = F.interpolate(condition, scale_factor=4, mode="bicubic", align_corners=False)
-    return h + F.conv2d(up, sd["lr_upsampler.1.weight"], sd["lr_upsampler.1.bias"], padding=1)
+    return h + _conv3(up, sd["lr_upsampler.1.weight"], sd["lr_upsampler.1.bias"], emulate_bf16)
 
 
 def psnr(a: torch.Tensor, b: torch.Tensor, peak: float = 1.0) -> float:

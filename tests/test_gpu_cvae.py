@@ -141,3 +141,36 @@ def test_vgg_perceptual_loss_on_the_conv_core():
     print("perceptual loss", loss.item(), "reference arithmetic", ref.item())
     assert abs(loss.item() - ref.item()) < 5e-3 * abs(ref.item())
     assert rel_l2(x.grad.cpu(), xr.grad) < 0.1
+
+
+def test_cvae_gradients_like_for_like():
+    """The gradients of every trained parameter against autograd through the oracle run with the HIP path's rounding points
+    (bf16 operands of the eight 3x3 convs): the comparison above, against the fp32 run, is bounded at 15 % by LeakyReLU
+    slopes flipping under bf16 rounding in front of the BatchNorm layers; like for like the median tensor is within 2 %."""
+    sd = O.make_cvae_state(23, 64)
+    net = CVAE(latent_dim=64)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    x = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(79)
+    out, mu, logvar = net(x.to(DEV))
+    torch.manual_seed(79)
+    eps = torch.randn_like(mu)
+    ref_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running_" not in k) for k, v in sd.items()}
+    rmu, rlv, rskips = O.cvae_encode(ref_sd, x, True, emulate_bf16=True)
+    rout = O.cvae_decode(ref_sd, rmu + eps.cpu() * torch.exp(0.5 * rlv), x, rskips, True, emulate_bf16=True)
+    target = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(9))
+
+    def loss(o, m, lv, t):
+        return (o - t).pow(2).mean() + 1e-3 * (-0.5 * (1 + lv - m.pow(2) - lv.exp()).sum(1).mean())
+
+    loss(out, mu, logvar, target.to(DEV)).backward()
+    loss(rout, rmu, rlv, target).backward()
+    cancelled = {f"{b}.0.bias" for b in ("enc_conv2", "enc_conv3", "enc_conv4", "dec_conv1", "dec_conv2", "dec_conv3",
+                                         "upsample1", "upsample2")}
+    errs = sorted(((rel_l2(prm.grad.cpu(), ref_sd[name].grad), name) for name, prm in net.named_parameters()
+                   if prm.grad is not None and name not in cancelled), reverse=True)
+    print("CVAE like for like: worst", errs[:4], " median", errs[len(errs) // 2])
+    # measured: 7.3 % on the tensors at the bottom of the decoder (their gradients cross every BatchNorm above), 1.6 % median
+    assert errs[0][0] < 0.10, errs[:4]
+    assert errs[len(errs) // 2][0] < 3e-2
