@@ -659,9 +659,13 @@ void wgrad_geometry(int cin, int N, int H, int W, int *chunks, int *G) {
     const int cin_units = (cin + 7) / 8;
     *chunks = (cin_units + 3) / 4;
     const long long tiles = (long long)N * ((H + WTH - 1) / WTH) * ((W + 31) / 32);
-    long long g = tiles / 8;   // eight tiles per workgroup: the partial slabs, not the MFMAs, are what a launch moves
-    // (measured at the training shape, 128 tiles: seven tiles per workgroup, 494 workgroups instead of 416, makes the
-    // pixel iteration 11 % slower)
+    // sixteen tiles per workgroup (SR355_WGRAD_TILES overrides): every workgroup ends by writing a 36.9 KB slab that the
+    // reduction reads again, and at eight tiles that traffic was half of a wide layer's launch; measured per
+    // discriminator / VGG layer at 32 images and on the training iterations: 8 -> 16 tiles 1,834 -> 1,554 us summed over the
+    // layers, pixel iteration -1.8 %, adversarial -2 %; 32 is level with 16 overall and worse at the training shape (128
+    // tiles), 64 is 35 % slower.
+    static const int per_wg = [] { const char *e = getenv("SR355_WGRAD_TILES"); const int v = e ? atoi(e) : 16; return v < 1 ? 16 : v; }();
+    long long g = tiles / per_wg;
     const long long cap = 768 / *chunks;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -710,10 +714,10 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
 // dw[b][k] / db[b][k] receive conv(k+1)'s gradients; conv5's is scaled by s5[b], the growth convs' by s_growth.
 // Block b's slabs start at slabs + b * wgrad_block_workspace_bytes.  With `defer` (room for 5 * n_blocks jobs) the
 // reduction is left to the caller: launch_wgrad_reduce_jobs on the collected jobs.
-// At training-patch sizes a block's launch is 416 workgroups of eight tiles on 256 CUs, bound by the latency of each
-// tile's fetch: several blocks in one launch keep every CU supplied with resident workgroups (measured 19 -> 14.7 us per
-// block with three blocks a launch at 16 patches of 32 x 32; six blocks are 2,496 workgroups = 4.9 rounds of the 512 the
-// chip holds, three are 2.4).
+// At training-patch sizes (16 patches of 32 x 32: 128 tiles) a block's launch is a few hundred workgroups on 256 CUs,
+// bound by the latency of each tile's fetch: several blocks in one launch keep every CU supplied with resident
+// workgroups (measured with eight tiles a workgroup: 19 us per block alone, 14.7 with three blocks a launch, 12.9 with six;
+// at sixteen tiles a workgroup six blocks are 1,248 workgroups, 2.4 rounds of the 512 the chip holds).
 int launch_wgrad3x3_blocks(int n_blocks, const void *const *act, const void *const *stack, int units, int nf, int gc,
                            int N, int H, int W, const float *s5, float *const (*dw)[5], float *const (*db)[5],
                            float *slabs, hipStream_t stream, WgradReduceJob *defer, float s_growth) {
