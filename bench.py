@@ -533,7 +533,7 @@ def train_kernel_roofline(dev, batches=(16, 32, 64), size=32):
     bytes_px = {"dense_block_band (forward)": 2 * nf + 4 * nf + 4 * 2 * gc + 2 * nf + 4 * nf,
                 "dense_block_band_gated (data gradient)": 2 * nf + 4 * 2 * gc + 4 * 2 * gc + 4 * nf,
                 "wgrad3x3_kernel_mb1 (five convs) + reduction": 2 * 2 * (nf + 4 * gc)}
-    WGRAD6 = "wgrad3x3_kernel_mb1 + reduction, six blocks per launch, per block"
+    WGRAD6 = "wgrad3x3_kernel_mb1 + reduction, nine blocks per launch, per block"
     bytes_px[WGRAD6] = bytes_px["wgrad3x3_kernel_mb1 (five convs) + reduction"]
     out = {"shape": f"LR patches of {size}x{size}, one dense block (64 + 4 x 32 channels)", "flop_per_pixel": flop_px,
            "algorithmic_bytes_per_pixel": bytes_px, "peak_tflops": PEAK_BF16_TFLOPS, "peak_gbps": PEAK_HBM_GBPS,
@@ -568,18 +568,18 @@ def train_kernel_roofline(dev, batches=(16, 32, 64), size=32):
         need = ops._lib.lib().sr355_dense_block_wgrad_workspace_bytes(nf, gc, B, size, size)
         wsb = torch.empty(need, dtype=torch.uint8, device=dev)
         wg = ops.dense_wgrad_args(buf, stack, nf, gc, 1.0, 0.2, dws, dbs, wsb)
-        # six blocks per launch, each with buffers of its own: the form the generator's backward runs (two RRDBs' weight
-        # gradients behind the sixth block's data gradients); the figure is per block
-        six_ws = torch.empty(6 * need, dtype=torch.uint8, device=dev)
+        # nine blocks per launch, each with buffers of its own: the form the generator's backward runs (three RRDBs' weight
+        # gradients behind the ninth block's data gradients); the figure is per block
+        six_ws = torch.empty(9 * need, dtype=torch.uint8, device=dev)
         six_bufs = [(torch.randn((B, size, units, size, 8), generator=g, device=dev).to(torch.bfloat16),
-                     torch.randn((B, size, units, size, 8), generator=g, device=dev).to(torch.bfloat16)) for _ in range(6)]
+                     torch.randn((B, size, units, size, 8), generator=g, device=dev).to(torch.bfloat16)) for _ in range(9)]
         six = [ops.dense_wgrad_args(a_, s_, nf, gc, 1.0, 0.2, dws, dbs, six_ws) for a_, s_ in six_bufs]
         px = B * size * size
         rows = {}
         for name, launch, arg, per in (("dense_block_band (forward)", ops.launch_dense_block, fwd, 1),
                                        ("dense_block_band_gated (data gradient)", ops.launch_dense_block, gated, 1),
                                        ("wgrad3x3_kernel_mb1 (five convs) + reduction", ops.launch_dense_wgrad, wg, 1),
-                                       (WGRAD6, ops.launch_dense_wgrad_blocks, six, 6)):
+                                       (WGRAD6, ops.launch_dense_wgrad_blocks, six, 9)):
             sec = timed(launch, arg) / per
             rows[name] = {"avg_launch_us": round(sec * 1e6, 2), "tflops": round(flop_px * px / sec / 1e12, 1),
                           "mfma_frac": round(flop_px * px / sec / 1e12 / PEAK_BF16_TFLOPS, 4),

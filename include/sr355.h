@@ -233,12 +233,12 @@ typedef struct sr355_dense_wgrad_args {
 size_t sr355_dense_block_wgrad_workspace_bytes(int num_features, int growth_channels, int N, int H, int W);
 int sr355_dense_block_wgrad(const sr355_dense_wgrad_args *args, void *stream);
 /* The same for n_blocks (1 .. SR355_DENSE_WGRAD_MAX_BLOCKS) dense blocks of one shape in ONE launch + one reduction: the
- * blocks of an RRDB (/root/reference/esrgan/models/esrgan_model.py:30-33), or of two.  At training-patch sizes one
- * block's launch cannot keep the chip busy (a few hundred workgroups bound by the latency of their tile fetches); six blocks
- * per launch take 12 us per block where one takes 19.  args[0 .. n_blocks): every block has its own act / stack / dw / db;
+ * blocks of an RRDB (/root/reference/esrgan/models/esrgan_model.py:30-33), or of two or three.  At training-patch sizes one
+ * block's launch cannot keep the chip busy (a few hundred workgroups bound by the latency of their tile fetches); nine
+ * blocks per launch take 10 us per block where one takes 19.  args[0 .. n_blocks): every block has its own act / stack / dw / db;
  * shape, units and growth_scale must agree; the scratch is args[0].workspace_dev, n_blocks times the one-block size
  * (the other entries' workspace fields are ignored).  Results are bit-identical to n_blocks single calls. */
-#define SR355_DENSE_WGRAD_MAX_BLOCKS 6
+#define SR355_DENSE_WGRAD_MAX_BLOCKS 9
 int sr355_dense_blocks_wgrad(const sr355_dense_wgrad_args *args, int n_blocks, void *stream);
 
 /* The same gradient on the exact-fp32 path (precision="fp32" modules under loss.backward(),

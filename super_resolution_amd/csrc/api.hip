@@ -1730,7 +1730,7 @@ int sr355_generator_pack_bwd(const sr355_generator_cfg *cfg, const float *const 
 
 // Backward workspace.
 struct BwdWs {
-    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, GBx[4], dfea, slabs, total;
+    size_t dout, G3, G2, G1u, G1, G0u, gL1, gL1b, gT, gR, GB0, GB1, GB2, GBx[7], dfea, slabs, total;
 };
 
 static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int N, int H, int W) {
@@ -1756,10 +1756,10 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     b.GB0 = take(P * ws.blk_units * 16);
     b.GB1 = take(P * ws.blk_units * 16);
     b.GB2 = take(P * ws.blk_units * 16);   // third gradient stack of the one-launch dense-block backward
-    // four more where the dense blocks run as one launch each (narrow images): the stacks of two RRDBs' six blocks stay whole
-    // until their weight gradients have been issued as one launch
+    // seven more where the dense blocks run as one launch each (narrow images): the stacks of three RRDBs' nine blocks stay
+    // whole until their weight gradients have been issued as one launch
     const bool narrow = use_dense_fused(&c, N, H, W);
-    for (int k = 0; k < 4; ++k) b.GBx[k] = take(narrow ? P * ws.blk_units * 16 : 0);
+    for (int k = 0; k < 7; ++k) b.GBx[k] = take(narrow ? P * ws.blk_units * 16 : 0);
     b.dfea = take(P * ws.nf_units * 16);
     size_t slab = 0;
     const int nf = c.num_features, gc = c.growth_channels;
@@ -1776,7 +1776,7 @@ static BwdWs carve_bwd_ws(const sr355_generator_cfg &c, const Workspace &ws, int
     // a dense block's five at once, and three blocks' worth: an RRDB's reductions run as one launch
     const size_t block_slabs = wgrad_block_workspace_bytes(nf, gc, N, H, W);
     if (3 * block_slabs > slab) slab = 3 * block_slabs;
-    if (narrow && 6 * block_slabs > slab) slab = 6 * block_slabs;
+    if (narrow && 9 * block_slabs > slab) slab = 9 * block_slabs;
     b.slabs = take(slab);
     b.total = off;
     return b;
@@ -1943,12 +1943,14 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     // One-launch dense blocks with the weight gradients on the caller's stream: the weight gradients of an RRDB's three
     // blocks go out as ONE launch behind the third block's data gradients (their workgroups keep every CU busy where one
     // block's cannot); the three stacks then have to stay whole until that launch, hence a fourth buffer.
-    // SR355_WGRAD_RRDB = RRDBs per weight-gradient launch (0: one launch per dense block, 1, 2; default 2)
-    static const int rrdb_knob = [] { const char *e = getenv("SR355_WGRAD_RRDB"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : v > 2 ? 2 : v; }();
+    // SR355_WGRAD_RRDB = RRDBs per weight-gradient launch (0: one launch per dense block, 1, 2, 3; default 3: measured
+    // 5.85 / 5.12 / 4.80 / 4.71 ms per pixel iteration at 16 patches of 32 x 32 with sixteen tiles a workgroup)
+    static const int rrdb_knob = [] { const char *e = getenv("SR355_WGRAD_RRDB"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : v > 3 ? 3 : v; }();
     const bool rrdb_wgrad = fused && !ss && rrdb_knob > 0;
     const int rr_max = 3 * rrdb_knob;              // dense blocks per weight-gradient launch
     const int n_gb = rrdb_wgrad ? rr_max + 1 : fused ? 3 : 2;
-    unsigned char *GB[7] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2, wb + bw.GBx[0], wb + bw.GBx[1], wb + bw.GBx[2], wb + bw.GBx[3]};
+    unsigned char *GB[10] = {wb + bw.GB0, wb + bw.GB1, wb + bw.GB2, wb + bw.GBx[0], wb + bw.GBx[1], wb + bw.GBx[2], wb + bw.GBx[3],
+                             wb + bw.GBx[4], wb + bw.GBx[5], wb + bw.GBx[6]};
     if (phase_begin == 0) {
     // grad_out -> blocked bf16
     if ((rc = launch_nchw_to_blocked(grad_out_nchw, N, cfg->out_channels, 4 * H, 4 * W, dt, wb + bw.dout, ou, 0, stream)))
@@ -1987,11 +1989,11 @@ int sr355_generator_backward_range(const sr355_generator_cfg *cfg, const void *p
     }   // phase 0
     // RRDBs in reverse (:35-39, :18-24); the gradient-stack buffer alternates once per dense block
     int blocks_done = 0;   // dense blocks of this call whose wgrads have been issued
-    WgradReduceJob pending[30];
+    WgradReduceJob pending[45];
     int n_pending = 0;
-    const void *rr_act[6] = {}, *rr_stack[6] = {};   // the blocks whose weight gradients wait for their launch, in the order of
-    float rr_s5[6] = {};                              // their data gradients
-    float *rr_dw[6][5] = {}, *rr_db[6][5] = {};
+    const void *rr_act[9] = {}, *rr_stack[9] = {};   // the blocks whose weight gradients wait for their launch, in the order of
+    float rr_s5[9] = {};                              // their data gradients
+    float *rr_dw[9][5] = {}, *rr_db[9][5] = {};
     int rr_n = 0;
     auto rr_flush = [&]() -> int {
         if (rr_n == 0) return SR355_OK;

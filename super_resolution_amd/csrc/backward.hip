@@ -159,7 +159,7 @@ __global__ void pool2x2_kernel(const T *__restrict__ in, int N, int H, int W, in
 // Weight gradient.  Workgroup = 3 waves; wave ky owns the three taps of kernel row ky.  Work item =
 // (4 x 32 pixel tile, chunk of 32 input channels); a workgroup sums its items in registers and
 // writes one slab [9][CO][32] at the end.
-constexpr int WGRAD_MAX_JOBS = 36;   // convs (or 32-output slices of one conv) a batched launch takes: six dense blocks of six
+constexpr int WGRAD_MAX_JOBS = 54;   // convs (or 32-output slices of one conv) a batched launch takes: nine dense blocks of six
 struct WgradArgs {
     const unsigned char *in;   // blocked bf16 activations (conv input)
     const unsigned char *dy;   // blocked bf16 gradient of the conv output
@@ -717,7 +717,7 @@ size_t wgrad_block_workspace_bytes(int nf, int gc, int N, int H, int W) {
 // At training-patch sizes (16 patches of 32 x 32: 128 tiles) a block's launch is a few hundred workgroups on 256 CUs,
 // bound by the latency of each tile's fetch: several blocks in one launch keep every CU supplied with resident
 // workgroups (measured with eight tiles a workgroup: 19 us per block alone, 14.7 with three blocks a launch, 12.9 with six;
-// at sixteen tiles a workgroup six blocks are 1,248 workgroups, 2.4 rounds of the 512 the chip holds).
+// at sixteen tiles a workgroup nine blocks are 1,872 workgroups, 3.7 rounds of the 512 the chip holds).
 int launch_wgrad3x3_blocks(int n_blocks, const void *const *act, const void *const *stack, int units, int nf, int gc,
                            int N, int H, int W, const float *s5, float *const (*dw)[5], float *const (*db)[5],
                            float *slabs, hipStream_t stream, WgradReduceJob *defer, float s_growth) {

@@ -268,11 +268,11 @@ def launch_dense_wgrad(a: DenseWgradArgs) -> None:
     check(_lib.lib().sr355_dense_block_wgrad(C.byref(a), _stream()), "sr355_dense_block_wgrad")
 
 
-DENSE_WGRAD_MAX_BLOCKS = 6      # SR355_DENSE_WGRAD_MAX_BLOCKS of include/sr355.h
+DENSE_WGRAD_MAX_BLOCKS = 9      # SR355_DENSE_WGRAD_MAX_BLOCKS of include/sr355.h
 
 
 def launch_dense_wgrad_blocks(blocks: Sequence[DenseWgradArgs]) -> None:
-    """sr355_dense_blocks_wgrad: the weight gradients of up to six dense blocks of one shape (an RRDB's, or two RRDBs')
+    """sr355_dense_blocks_wgrad: the weight gradients of up to nine dense blocks of one shape (an RRDB's, or two or three RRDBs')
     as one launch and one reduction; ``blocks[0].workspace`` must hold ``len(blocks)`` times the one-block size."""
     if not 1 <= len(blocks) <= DENSE_WGRAD_MAX_BLOCKS:
         raise RuntimeError(f"dense_blocks_wgrad takes 1 to {DENSE_WGRAD_MAX_BLOCKS} blocks")

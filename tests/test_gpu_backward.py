@@ -182,7 +182,7 @@ def test_dense_block_weight_gradients_in_one_launch_equal_five_launches(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_blocks", [2, 3, 6])
+@pytest.mark.parametrize("n_blocks", [2, 3, 6, 9])
 def test_several_dense_blocks_in_one_weight_gradient_launch_equal_single_launches(n_blocks):
     """sr355_dense_blocks_wgrad: the weight gradients of the dense blocks of one or two RRDBs
     (/root/reference/esrgan/models/esrgan_model.py:30-33) as one launch + one reduction, through the C ABI, against one
