@@ -51,7 +51,7 @@ extern "C" {
 #define SR355_PACK_F16 3    /* sr355_pack_weight only (bf16 dtype): one weight image stored as IEEE fp16, for a
                               conv run with f16_in = 1 */
 
-#define SR355_ABI_VERSION 17
+#define SR355_ABI_VERSION 18
 
 int sr355_abi_version(void);
 const char *sr355_last_error(void);
@@ -177,6 +177,23 @@ int sr355_dense_block_fwd(const sr355_dense_block_args *args, void *stream);
 int sr355_pack_weight_transposed(const float *w_oihw_dev, int cout, int cin, int ci_lo, int n_out,
                                  int dtype, float scale, void *w_packed_dev, int packed_units,
                                  int unit_off, size_t w_packed_bytes, void *stream);
+/* Several packings in one launch each (the nine convs of the discriminator, esrgan_model.py:74-84, repack after every
+ * optimizer step; one launch per conv and form is eighteen launches of a few microseconds): `jobs[i]` are the arguments
+ * of one sr355_pack_weight / sr355_pack_weight_transposed call, the results are those calls'. */
+typedef struct sr355_pack_job {
+    const float *w_dev, *bias_dev;   /* OIHW fp32 weight, bias (may be NULL: zeros) */
+    void *wp_dev; size_t wp_bytes;   /* sr355_packed_weight_bytes(cout, cin, dtype, split) */
+    float *bp_dev;                   /* round_up(cout, 32) floats */
+    int cout, cin, split;
+} sr355_pack_job;
+int sr355_pack_weights(const sr355_pack_job *jobs, int n, int dtype, void *stream);
+typedef struct sr355_pack_t_job {
+    const float *w_dev;
+    void *wp_dev; size_t wp_bytes;
+    int cout, cin, ci_lo, n_out, packed_units, unit_off;
+    float scale;
+} sr355_pack_t_job;
+int sr355_pack_weights_transposed(const sr355_pack_t_job *jobs, int n, int dtype, void *stream);
 
 /* Adjoint of the nearest x2 upsample fused in front of a conv: out[y][x] = sum of the 2x2 block of
  * `in_dev` ([N][2H][units][2W] blocked), optionally gated by sign(mask) (LeakyReLU backward), written

@@ -16,7 +16,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 SPLIT_NONE, SPLIT_WEIGHT, SPLIT_INPUT = 0, 1, 2
 STATIC_SCRATCH_BYTES = 16 << 20   # SR355_STATIC_SCRATCH_BYTES
 PACK_F16 = 3     # sr355_pack_weight: one weight image stored as fp16
@@ -29,7 +29,7 @@ EXPORTS = (
     "sr355_nchw_to_blocked", "sr355_blocked_to_nchw",
     "sr355_packed_weight_bytes", "sr355_pack_weight",
     "sr355_conv3x3_fwd", "sr355_dense_block_fwd",
-    "sr355_pack_weight_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
+    "sr355_pack_weight_transposed", "sr355_pack_weights", "sr355_pack_weights_transposed", "sr355_pool2x2_sum", "sr355_wgrad_workspace_bytes", "sr355_conv3x3_wgrad",
     "sr355_conv3x3_wgrad_static", "sr355_wgrad_f32_workspace_bytes", "sr355_conv3x3_wgrad_f32",
     "sr355_generator_num_convs", "sr355_generator_packed_bytes", "sr355_generator_pack",
     "sr355_generator_workspace_bytes", "sr355_generator_forward", "sr355_generator_forward_u8",
@@ -88,6 +88,19 @@ class DenseBlockArgs(C.Structure):
         ("out_units", C.c_int), ("out_unit_off", C.c_int),
         ("out_f32_dev", C.c_void_p),
     ]
+
+
+class PackJob(C.Structure):
+    """Mirror of ``sr355_pack_job``."""
+    _fields_ = [("w_dev", C.c_void_p), ("bias_dev", C.c_void_p), ("wp_dev", C.c_void_p), ("wp_bytes", C.c_size_t),
+                ("bp_dev", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("split", C.c_int)]
+
+
+class PackTJob(C.Structure):
+    """Mirror of ``sr355_pack_t_job``."""
+    _fields_ = [("w_dev", C.c_void_p), ("wp_dev", C.c_void_p), ("wp_bytes", C.c_size_t), ("cout", C.c_int),
+                ("cin", C.c_int), ("ci_lo", C.c_int), ("n_out", C.c_int), ("packed_units", C.c_int),
+                ("unit_off", C.c_int), ("scale", C.c_float)]
 
 
 class WgradArgs(C.Structure):
@@ -164,6 +177,8 @@ def lib() -> C.CDLL:
     L.sr355_conv3x3_fwd.argtypes = [C.POINTER(ConvArgs), vp]
     L.sr355_dense_block_fwd.argtypes = [C.POINTER(DenseBlockArgs), vp]
     L.sr355_pack_weight_transposed.argtypes = [vp, i, i, i, i, i, f, vp, i, i, sz, vp]
+    L.sr355_pack_weights.argtypes = [C.POINTER(PackJob), i, i, vp]
+    L.sr355_pack_weights_transposed.argtypes = [C.POINTER(PackTJob), i, i, vp]
     L.sr355_pool2x2_sum.argtypes = [vp, sz, i, i, i, i, i, vp, sz, i, i, f, vp, sz, vp, sz, i, i, vp]
     L.sr355_wgrad_workspace_bytes.argtypes = [i, i, i, i, i]
     L.sr355_wgrad_workspace_bytes.restype = sz

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 from torch.autograd.function import once_differentiable
@@ -132,6 +134,34 @@ def _packs_of(weight: Tensor) -> _PackedWeights:
         p = _PackedWeights()
         weight._sr355_packs = p
     return p
+
+
+def prepare_packs(convs, backward: bool) -> None:
+    """Brings the packs of several convs up to date in ONE launch per form (and one zero fill) instead of one launch, one
+    zero fill and one allocation per conv: a network repacks all of its convs after every optimizer step.  ``convs`` are
+    ``nn.Conv2d`` modules (3x3); ``backward`` also prepares the whole-conv data-gradient packs.  What is left to the
+    per-conv path (a split-cotangent pack) is built there on first use, as before."""
+    if os.environ.get("SR355_BATCH_PACKS", "1") == "0":      # (measurement knob: one launch per conv and form, as before)
+        return
+    stale_f, stale_b = [], []
+    for c in convs:
+        w, b = c.weight, c.bias
+        if w.dtype != torch.float32 or b is None or not w.is_cuda:
+            return                                   # the per-conv path reports what is wrong with such a module
+        packs = _packs_of(w)
+        packs._sync(w, b)
+        if packs.fwd is None:
+            stale_f.append((packs, w, b))
+        if backward and packs.bwd is None:
+            stale_b.append((packs, w))
+    if len(stale_f) > 1:
+        built = ops.pack_weights_batch([w.detach() for _p, w, _b in stale_f], [b.detach() for _p, _w, b in stale_f], DTYPE_BF16)
+        for (packs, _w, _b), pair in zip(stale_f, built):
+            packs.fwd = pair
+    if len(stale_b) > 1:
+        built = ops.pack_weights_transposed_batch([w.detach() for _p, w in stale_b], DTYPE_BF16)
+        for (packs, _w), pair in zip(stale_b, built):
+            packs.bwd = pair
 
 
 def _conv_forward(x: Tensor, weight: Tensor, bias: Tensor, slope: float, out_kind: str, stride: int) -> Tensor:

@@ -208,6 +208,26 @@ int sr355_pack_weight(const float *w, const float *bias, int cout, int cin, int 
     return launch_pack_weight(w, bias, cout, cin, dtype, split, wp, bp, (hipStream_t)stream);
 }
 
+int sr355_pack_weights(const sr355_pack_job *jobs, int n, int dtype, void *stream) {
+    if (!jobs || n < 1 || n > 4096) {
+        set_error("pack_weights: jobs is null or n=%d outside [1, 4096]", n);
+        return SR355_ERR_INVALID;
+    }
+    std::vector<PackJob> v((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const sr355_pack_job &j = jobs[i];
+        const size_t need = sr355_packed_weight_bytes(j.cout, j.cin, dtype, j.split);
+        if (!need || !j.w_dev || !j.wp_dev || !aligned16(j.wp_dev) || j.wp_bytes < need) {
+            set_error("pack_weights: job %d: bad arguments (cout=%d cin=%d dtype=%d bytes=%zu need=%zu)", i, j.cout, j.cin,
+                      dtype, j.wp_bytes, need);
+            return SR355_ERR_INVALID;
+        }
+        const bool f16 = dtype == SR355_DTYPE_BF16 && j.split == SR355_PACK_F16;
+        v[i] = PackJob{j.w_dev, j.bias_dev, j.wp_dev, j.bp_dev, j.cout, j.cin, f16 ? 0 : j.split, f16 ? 1 : 0};
+    }
+    return launch_pack_weight_batch(v.data(), n, dtype, (hipStream_t)stream);
+}
+
 int sr355_conv3x3_fwd(const sr355_conv_args *p, void *stream) {
     if (!p) {
         set_error("conv3x3_fwd: args is null");
@@ -457,6 +477,27 @@ int sr355_pack_weight_transposed(const float *w, int cout, int cin, int ci_lo, i
     }
     return launch_pack_weight_t(w, cout, cin, ci_lo, n_out, dtype, scale, wp, unit_off, cout_pad_for(n_out),
                                 (hipStream_t)stream);
+}
+
+int sr355_pack_weights_transposed(const sr355_pack_t_job *jobs, int n, int dtype, void *stream) {
+    const int cpu = unit_channels(dtype);
+    if (!jobs || n < 1 || n > 4096 || cpu < 0) {
+        set_error("pack_weights_transposed: jobs is null, n=%d outside [1, 4096] or unknown dtype %d", n, dtype);
+        return SR355_ERR_INVALID;
+    }
+    std::vector<PackTJob> v((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const sr355_pack_t_job &j = jobs[i];
+        if (!j.w_dev || !j.wp_dev || !aligned16(j.wp_dev) || j.cout < 1 || j.cin < 1 || j.ci_lo < 0 || j.n_out < 1 ||
+            j.ci_lo + j.n_out > j.cin || j.unit_off < 0 || j.unit_off + (j.cout + cpu - 1) / cpu > j.packed_units ||
+            j.wp_bytes < (size_t)j.packed_units * 9 * cout_pad_for(j.n_out) * 16) {
+            set_error("pack_weights_transposed: job %d: bad arguments (cout=%d cin=%d ci_lo=%d n_out=%d units=%d off=%d)", i,
+                      j.cout, j.cin, j.ci_lo, j.n_out, j.packed_units, j.unit_off);
+            return SR355_ERR_INVALID;
+        }
+        v[i] = PackTJob{j.w_dev, j.wp_dev, j.cout, j.cin, j.ci_lo, j.n_out, j.unit_off, cout_pad_for(j.n_out), j.scale};
+    }
+    return launch_pack_weight_t_batch(v.data(), n, dtype, (hipStream_t)stream);
 }
 
 int sr355_pool2x2_sum(const void *in, size_t in_bytes, int N, int H, int W, int units, int dtype, const void *mask,

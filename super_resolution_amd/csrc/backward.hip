@@ -613,11 +613,18 @@ int launch_pack_weight_t_batch(const PackTJob *jobs, int n, int dtype, hipStream
     for (int at = 0; at < n; at += PACK_BATCH) {
         PackTJobTable t;
         const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
-        for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
+        size_t biggest = 0;      // items of the largest job: the blocks of a row stride over their job's items
+        for (int i = 0; i < m; ++i) {
+            t.j[i] = jobs[at + i];
+            const size_t items = (size_t)((jobs[at + i].Co + 7) / 8) * 9 * jobs[at + i].cout_pad;
+            if (items > biggest) biggest = items;
+        }
+        unsigned gx = (unsigned)((biggest + 1023) / 1024);
+        gx = gx < 32 ? 32 : gx > 512 ? 512 : gx;
         if (dtype == SR355_DTYPE_BF16)
-            hipLaunchKernelGGL(pack_weight_t_batch_kernel<__bf16>, dim3(32, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<__bf16>, dim3(gx, m), dim3(256), 0, stream, t);
         else
-            hipLaunchKernelGGL(pack_weight_t_batch_kernel<float>, dim3(32, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_t_batch_kernel<float>, dim3(gx, m), dim3(256), 0, stream, t);
         if (check_hip(hipGetLastError(), "pack_weight_t batch launch")) return SR355_ERR_HIP;
     }
     return SR355_OK;

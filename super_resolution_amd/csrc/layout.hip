@@ -280,11 +280,19 @@ int launch_pack_weight_batch(const PackJob *jobs, int n, int dtype, hipStream_t 
     for (int at = 0; at < n; at += PACK_BATCH) {
         PackJobTable t;
         const int m = n - at < PACK_BATCH ? n - at : PACK_BATCH;
-        for (int i = 0; i < m; ++i) t.j[i] = jobs[at + i];
+        size_t biggest = 0;      // items of the largest job: the blocks of a row stride over their job's items
+        for (int i = 0; i < m; ++i) {
+            t.j[i] = jobs[at + i];
+            const size_t items = (size_t)((jobs[at + i].cin + 7) / 8 + 1) * 9 * ((jobs[at + i].cout + 31) / 32 * 32);
+            if (items > biggest) biggest = items;
+        }
+        // 48 blocks a job serve the generator's convs (at most 192 x 64); a 512 x 512 conv wants ten times as many
+        unsigned gx = (unsigned)((biggest + 1023) / 1024);
+        gx = gx < 48 ? 48 : gx > 512 ? 512 : gx;
         if (dtype == SR355_DTYPE_BF16)
-            hipLaunchKernelGGL(pack_weight_batch_kernel<__bf16>, dim3(48, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_batch_kernel<__bf16>, dim3(gx, m), dim3(256), 0, stream, t);
         else
-            hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(48, m), dim3(256), 0, stream, t);
+            hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(gx, m), dim3(256), 0, stream, t);
         if (check_hip(hipGetLastError(), "pack_weight batch launch")) return SR355_ERR_HIP;
     }
     return SR355_OK;

@@ -110,6 +110,7 @@ class Discriminator(nn.Module):
             return self._empty_result(img)
         self._check_batch(int(img.shape[0]), int(img.shape[2]), int(img.shape[3]))
         params = [p for p in self.parameters()]
+        cc.prepare_packs([m for m in self.model if isinstance(m, nn.Conv2d)], torch.is_grad_enabled())
         if torch.is_grad_enabled() and (img.requires_grad or any(p.requires_grad for p in params)):
             # recorded: the whole network is one autograd node whose backward keeps the gradients between the layers
             # in fp32 wherever a BatchNorm's backward consumes them
@@ -129,6 +130,7 @@ class Discriminator(nn.Module):
             return self._empty_result(real), self._empty_result(fake)
         self._check_batch(int(real.shape[0]), int(real.shape[2]), int(real.shape[3]))
         params = [p for p in self.parameters()]
+        cc.prepare_packs([m for m in self.model if isinstance(m, nn.Conv2d)], torch.is_grad_enabled())
         n = int(real.shape[0])
         both = torch.cat([real, fake], dim=0)
         if torch.is_grad_enabled() and (both.requires_grad or any(p.requires_grad for p in params)):
@@ -246,13 +248,15 @@ class _DiscriminatorFunction(torch.autograd.Function):
                 cout = int(w.shape[0])
                 N, H, _q, W, _c = y32.shape
                 dyb = torch.empty((N, H, cout // 8, W, 8), dtype=torch.bfloat16, device=y32.device)
-                dgamma = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
-                dbeta = torch.empty((groups, cout), dtype=torch.float32, device=y32.device)
+                dgb = torch.empty((2, groups, cout), dtype=torch.float32, device=y32.device)
+                dgamma, dbeta = dgb[0], dgb[1]
                 g = g.contiguous()
                 ops.bn_lrelu_bwd_now(y32, g, bn.weight.detach(), bn.bias.detach(), mean, rstd, float(slope), training,
                                      dyb, dgamma, dbeta, 0, 0, groups)
-                dgamma = dgamma[0] if groups == 1 else dgamma.sum(0)
-                dbeta = dbeta[0] if groups == 1 else dbeta.sum(0)
+                if groups == 1:
+                    dgamma, dbeta = dgamma[0], dbeta[0]
+                else:                                  # the groups' contributions add up, as two calls would accumulate
+                    dgamma, dbeta = dgb.sum(1).unbind(0)
             dx, dw, db = cc._conv_backward(x, w, b, dyb, stride, need_dx, need_dw, dx_f32=dx_f32, dy_split=dy_split)
             grads.append([dw, db] if bn is None else [dw, db, dgamma, dbeta])
             g = dx

@@ -319,6 +319,70 @@ def _(w, ci_lo, n_out, scale, w_packed, packed_units, unit_off, dtype):
     return None
 
 
+def pack_weights_batch(weights: Sequence[Tensor], biases: Sequence[Tensor], dtype: int) -> List[Tuple[Tensor, Tensor]]:
+    """``pack_weight`` of several convs in one launch (sr355_pack_weights): the packed weights are slices of one byte buffer,
+    the padded biases slices of one fp32 buffer; same bytes as the single calls."""
+    _need_cuda(*weights, *biases)
+    L = _lib.lib()
+    n = len(weights)
+    sizes, pads = [], []
+    for w in weights:
+        if w.dtype != torch.float32 or w.dim() != 4 or w.shape[2:] != (3, 3) or not w.is_contiguous():
+            raise RuntimeError("pack_weights_batch expects contiguous fp32 [cout, cin, 3, 3] tensors")
+        nb = L.sr355_packed_weight_bytes(int(w.shape[0]), int(w.shape[1]), dtype, 0)
+        if nb == 0:
+            raise RuntimeError("pack_weights_batch: unsupported shape")
+        sizes.append((nb + 255) // 256 * 256)
+        pads.append((int(w.shape[0]) + 31) // 32 * 32)
+    dev = weights[0].device
+    blob = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    bias_blob = torch.empty(sum(pads), dtype=torch.float32, device=dev)
+    jobs = (_lib.PackJob * n)()
+    out, at, bat = [], 0, 0
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        wp, bp = blob[at:at + sizes[i]], bias_blob[bat:bat + pads[i]]
+        j = jobs[i]
+        j.w_dev, j.bias_dev, j.wp_dev, j.wp_bytes, j.bp_dev = w.data_ptr(), b.data_ptr(), wp.data_ptr(), sizes[i], bp.data_ptr()
+        j.cout, j.cin, j.split = int(w.shape[0]), int(w.shape[1]), 0
+        out.append((wp, bp))
+        at += sizes[i]
+        bat += pads[i]
+    with _on(dev):
+        check(L.sr355_pack_weights(jobs, n, dtype, _stream()), "sr355_pack_weights")
+    return out
+
+
+def pack_weights_transposed_batch(weights: Sequence[Tensor], dtype: int) -> List[Tuple[Tensor, Tensor]]:
+    """The whole-conv data-gradient packs (``pack_weight_transposed(w, 0, cin, 1.0, ...)``) of several convs in one launch
+    (sr355_pack_weights_transposed): slices of one zero-filled buffer, each with an all-zero bias of its output width."""
+    _need_cuda(*weights)
+    L = _lib.lib()
+    n = len(weights)
+    cpu = UNIT_CHANNELS[dtype]
+    geo = []
+    for w in weights:
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        n_out = (cin + 3) // 4 * 4                         # blocked outputs come in channel quads
+        units = ((cout + cpu - 1) // cpu + 1) // 2 * 2
+        pad = (n_out + 31) // 32 * 32
+        geo.append((cout, cin, units, pad, (units * 9 * pad * 16 + 255) // 256 * 256))
+    dev = weights[0].device
+    blob = torch.zeros(sum(g[4] for g in geo), dtype=torch.uint8, device=dev)
+    zero_bias = torch.zeros(max(g[3] for g in geo), dtype=torch.float32, device=dev)
+    jobs = (_lib.PackTJob * n)()
+    out, at = [], 0
+    for i, (w, (cout, cin, units, pad, nb)) in enumerate(zip(weights, geo)):
+        wt = blob[at:at + nb]
+        j = jobs[i]
+        j.w_dev, j.wp_dev, j.wp_bytes = w.data_ptr(), wt.data_ptr(), nb
+        j.cout, j.cin, j.ci_lo, j.n_out, j.packed_units, j.unit_off, j.scale = cout, cin, 0, cin, units, 0, 1.0
+        out.append((wt, zero_bias[:pad]))
+        at += nb
+    with _on(dev):
+        check(L.sr355_pack_weights_transposed(jobs, n, dtype, _stream()), "sr355_pack_weights_transposed")
+    return out
+
+
 @torch.library.custom_op("sr355::pool2x2_sum", mutates_args=("out_f32", "out_act"))
 def pool2x2_sum(x: Tensor, mask: Optional[Tensor], mask_unit_off: int, mask_slope: float,
                 out_f32: Optional[Tensor], out_act: Optional[Tensor], out_unit_off: int) -> None:

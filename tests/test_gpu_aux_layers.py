@@ -184,3 +184,38 @@ def test_grouped_batchnorm_is_the_separate_calls(case, dy_f32):
         mean = torch.empty(groups, C, device=DEV)
         ops.bn_lrelu_fwd(x, gamma, beta, 1e-5, 0.2, True, 0.1, None, None, None, mean, mean.clone(),
                          torch.empty((N, H, C // 8, W, 8), dtype=torch.bfloat16, device=DEV), 0, N + 1)
+
+
+def test_batched_weight_packs_are_the_single_packs():
+    """sr355_pack_weights / sr355_pack_weights_transposed (all convs of a network in one launch each) write the bytes of
+    the per-conv calls, and conv_core.prepare_packs installs them where the per-conv path looks."""
+    from super_resolution_amd import conv_core as cc, ops
+    from super_resolution_amd._lib import DTYPE_BF16
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 3), (64, 64), (128, 64), (1, 512), (48, 24), (136, 104)]
+    ws = [torch.randn(co, ci, 3, 3, generator=g).to(DEV) for co, ci in shapes]
+    bs = [torch.randn(co, generator=g).to(DEV) for co, _ci in shapes]
+    for (wp, bp), w, b in zip(ops.pack_weights_batch(ws, bs, DTYPE_BF16), ws, bs):
+        wp1, bp1 = ops.pack_weight(w, b, DTYPE_BF16)
+        assert torch.equal(wp[:wp1.numel()], wp1) and torch.equal(bp, bp1)
+    for (wt, zb), w in zip(ops.pack_weights_transposed_batch(ws, DTYPE_BF16), ws):
+        cout, cin = w.shape[0], w.shape[1]
+        units, n_out = cc.units_for(cout), (cin + 3) // 4 * 4
+        one = torch.zeros(units * 9 * ((n_out + 31) // 32 * 32) * 16, dtype=torch.uint8, device=DEV)
+        ops.pack_weight_transposed(w, 0, cin, 1.0, one, units, 0, DTYPE_BF16)
+        assert torch.equal(wt[:one.numel()], one) and not bool(zb.any()) and zb.numel() == (n_out + 31) // 32 * 32
+    convs = [torch.nn.Conv2d(ci, co, 3, 1, 1).to(DEV) for co, ci in shapes[:4]]
+    cc.prepare_packs(convs, True)
+    for c in convs:
+        packs = cc._packs_of(c.weight)
+        assert packs.fwd is not None and packs.bwd is not None
+        wp1, bp1 = ops.pack_weight(c.weight.detach(), c.bias.detach(), DTYPE_BF16)
+        got_w, got_b = packs.forward_pack(c.weight, c.bias)
+        assert torch.equal(got_w[:wp1.numel()], wp1) and torch.equal(got_b, bp1)
+    with torch.no_grad():
+        convs[1].weight.mul_(0.5)                      # a changed parameter is repacked, the others keep their packs
+    kept = cc._packs_of(convs[0].weight).fwd
+    cc.prepare_packs(convs, False)
+    assert cc._packs_of(convs[0].weight).fwd is kept
+    wp1, _ = ops.pack_weight(convs[1].weight.detach(), convs[1].bias.detach(), DTYPE_BF16)
+    assert torch.equal(cc._packs_of(convs[1].weight).forward_pack(convs[1].weight, convs[1].bias)[0][:wp1.numel()], wp1)
