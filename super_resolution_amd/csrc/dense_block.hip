@@ -372,17 +372,22 @@ __device__ __forceinline__ void db_run(DbRing &ring, const DbCtx &c, const v2u (
 
 // GATED: the data-gradient form (sign gates on steps 1..4); two kernels rather than one with both paths, which ran
 // 1.5 x slower in either form.
+// `buf`, `w0`, H, W, units, n_bands repeat a.buf, a.w[0], a.H, a.W, a.units, a.n_bands as kernel arguments of their own:
+// the dispatcher preloads the first kernel arguments into scalar registers (the build passes
+// -amdgpu-kernarg-preload-count for this file), so the input tile's and the first weight chunks' requests go out without
+// waiting for the argument block to arrive from memory.
 template <bool GATED>
-__device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
+__device__ __forceinline__ void dense_block_body(const unsigned char *buf_hot, const unsigned char *w0_hot, int H_hot,
+                                                 int W_hot, int units_hot, int n_bands_hot, const DenseArgs &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int H = a.H, W = a.W;
-    const int n = blockIdx.x / a.n_bands;
-    const int y0 = (blockIdx.x - n * a.n_bands) * DB_TH;
-    const int img_bytes = H * a.units * W * 16;
+    const int H = H_hot, W = W_hot;
+    const int n = blockIdx.x / n_bands_hot;
+    const int y0 = (blockIdx.x - n * n_bands_hot) * DB_TH;
+    const int img_bytes = H * units_hot * W * 16;
     DB_STAMP(0);
 
 #define DB_RSRC(PTR, LEN)                                                                                     \
@@ -432,7 +437,7 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
 
     // ---- input tile: 8 units x 12 rows x 34 pixels, piece j = k*4 + wave of 64 items each
     {
-        const __amdgpu_buffer_rsrc_t rs_in = DB_RSRC(a.buf + (size_t)n * img_bytes, img_bytes);
+        const __amdgpu_buffer_rsrc_t rs_in = DB_RSRC(buf_hot + (size_t)n * img_bytes, img_bytes);
 #pragma unroll
         for (int k = 0; k < DB_X_K; ++k) {
             const int j = k * 4 + wave;
@@ -443,7 +448,7 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
             const int px = p - row * DB_P;
             const int y = y0 - 5 + row, x = px - 1;
             const bool valid = i < DB_X_ITEMS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const int vo = valid ? ((y * a.units + u) * W + x) * 16 : DB_OOB;
+            const int vo = valid ? ((y * units_hot + u) * W + x) * 16 : DB_OOB;
             const int dst = j < DB_X_PIECES ? j * 1024 : DB_DUMMY_OFF;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void *)(smem + dst), 16, vo, 0, 0, 0);
         }
@@ -460,8 +465,8 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
     // ---- weight ring: flat chunk sequence over the five convs, four chunks issued ahead
     DbRing ring;
     ring.conv = 0, ring.local = 0, ring.left = 4, ring.slot = 0;
-    ring.w_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.w[0]);
-    ring.w_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.w[0] >> 32));
+    ring.w_lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)w0_hot);
+    ring.w_hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)w0_hot >> 32));
     ring.w_len = 4 * DB_CHUNK;
     DbCtx ctx = {a, smem, tid, wave, r, h, n, y0, img_bytes, {}, a.slope, a.mask_slope, H, W};
 #pragma unroll
@@ -507,8 +512,14 @@ __device__ __forceinline__ void dense_block_body(const DenseArgs &a) {
 #undef DB_RSRC
 }
 
-__global__ __launch_bounds__(256, 1) void dense_block_band(const DenseArgs a) { dense_block_body<false>(a); }
-__global__ __launch_bounds__(256, 1) void dense_block_band_gated(const DenseArgs a) { dense_block_body<true>(a); }
+__global__ __launch_bounds__(256, 1) void dense_block_band(const unsigned char *buf, const unsigned char *w0, int H, int W,
+                                                           int units, int n_bands, const DenseArgs a) {
+    dense_block_body<false>(buf, w0, H, W, units, n_bands, a);
+}
+__global__ __launch_bounds__(256, 1) void dense_block_band_gated(const unsigned char *buf, const unsigned char *w0, int H,
+                                                                 int W, int units, int n_bands, const DenseArgs a) {
+    dense_block_body<true>(buf, w0, H, W, units, n_bands, a);
+}
 
 bool dense_block_supported(int nf, int gc, int dtype, int W) {
     return dtype == SR355_DTYPE_BF16 && nf == 64 && gc == 32 && W >= 1 && W <= 32;
@@ -547,9 +558,11 @@ int launch_dense_block(const DenseArgs &a0, hipStream_t stream) {
     });
     if (check_hip(attr_err[dev], "hipFuncSetAttribute(dense_block_band)")) return SR355_ERR_HIP;
     if (a.mask)
-        hipLaunchKernelGGL(dense_block_band_gated, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(dense_block_band_gated, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream,
+                           (const unsigned char *)a.buf, (const unsigned char *)a.w[0], a.H, a.W, a.units, a.n_bands, a);
     else
-        hipLaunchKernelGGL(dense_block_band, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(dense_block_band, dim3((unsigned)grid), dim3(256), DB_LDS_BYTES, stream,
+                           (const unsigned char *)a.buf, (const unsigned char *)a.w[0], a.H, a.W, a.units, a.n_bands, a);
     return check_hip(hipGetLastError(), "dense block launch");
 }
 
